@@ -1,0 +1,426 @@
+// raymarch.hip — fused volumetric renderer for gfx950: ray set-up -> cam2world -> two tri-plane
+// gathers -> decoder MLPs (fp32 MFMA) -> depth-ordered alpha compositing, in ONE launch.
+//
+// Replaces steps 3-7 of G.synthesis:
+//   get_initial_rays_trig      training/volumetric_rendering.py:77-97   (points = d_cam * z)
+//   perturb_points             :99-105   (offset = (U - 0.5) * (z[1] - z[0]); z += offset; p += offset * d)
+//   transform_sampled_points   :108-136  (p_world = cam2world @ [p, 1])
+//   sample_from_triplane x2    dnnlib/util.py:580-617
+//   renderer.sample_voxel MLPs (source absent upstream; spec = DESIGN.md "decoder")
+//   fancy_integration          training/volumetric_rendering.py:34-74
+//
+// CDNA4 mapping
+//   * One wavefront owns one ray and walks it in tiles of 16 depth samples.  Lane l = (g = l>>4,
+//     j = l&15): sample j of the tile, channel group g.  The four lanes of a sample each fetch
+//     C/16 float4 chunks per bilinear tap from the channels_last planes (full 128-B line use at C=32).
+//   * The two MLPs run on v_mfma_f32_16x16x4_f32 (exact fp32) in the *transposed* form
+//     out^T[features x samples] = W[features x K] * act^T[K x samples]: the gathered features already
+//     sit in the MFMA B-operand layout (k = l>>4, n = l&15) and the D layout of layer 1
+//     (row = 4*(l>>4)+r, col = l&15) is again a valid B operand for layer 2 once K is enumerated as
+//     k(t, g) = 16*(t/4) + 4g + t%4 — so activations never leave registers between gather, layer 1,
+//     layer 2 and compositing.  Weights are re-ordered once per workgroup into LDS in A-operand order
+//     (one ds_read_b128 feeds 4 MFMAs).
+//   * Compositing: sigma is broadcast from the g = 0 lanes, alpha / transmittance are evaluated by a
+//     16-lane segmented shuffle scan with the running transmittance carried across tiles, each lane
+//     accumulates w * feature for the 16 output features it holds, a 4-step xor-shuffle reduction over
+//     the 16 samples closes the ray.  Nothing but the final [n, feat+seg, rays] image, depth and
+//     weight sum is written.
+//   * Persistent workgroups (3 per CU) take contiguous ray ranges; the range order is XCD-remapped so
+//     neighbouring rays (neighbouring plane lines) share one XCD L2.
+// Compulsory HBM traffic per image: 2 tri-planes + jitter/noise in + (feat+seg+2)*rays*4 out.  The
+// planes are cache resident (L2 4 MiB/XCD + 256 MiB MALL), so this kernel is bound by the L1/TA gather
+// rate and the fp32 MFMA rate, not by HBM — see DESIGN.md.
+#include "common.h"
+#include "triplane_tap.h"
+
+namespace ide3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int HID>
+struct RmCfg {
+    static constexpr int CPL = C / 16;          // float4 chunks per lane per tap
+    static constexpr int NF = C / 4;            // features (K elements) per lane
+    static constexpr int MT1 = HID / 16;        // layer-1 M tiles
+    static constexpr int MT2 = 2;               // layer-2 M tiles (<= 32 outputs)
+    // LDS carve per MLP, in floats
+    static constexpr int A1 = MT1 * CPL * 64 * 4;
+    static constexpr int A2 = MT2 * MT1 * 64 * 4;
+    static constexpr int B0 = MT1 * 16;         // [mt][g][4]
+    static constexpr int B1 = MT2 * 16;
+    static constexpr int MLP = A1 + A2 + B0 + B1;
+};
+
+// Re-order one MLP's weights into LDS (A-operand order).  w0 [HID, C], w1 [nout, HID] (nout <= 32).
+template <int C, int HID>
+__device__ void stage_mlp(float* __restrict__ s, const float* __restrict__ w0, const float* __restrict__ b0,
+                          const float* __restrict__ w1, const float* __restrict__ b1, int nout) {
+    using K = RmCfg<C, HID>;
+    float* a1 = s; float* a2 = a1 + K::A1; float* sb0 = a2 + K::A2; float* sb1 = sb0 + K::B0;
+    for (int i = threadIdx.x; i < K::A1; i += blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+        const int ci = rest % K::CPL, mt = rest / K::CPL;
+        const int row = 16 * mt + (lane & 15), col = 4 * ((lane >> 4) + 4 * ci) + e;
+        a1[i] = w0[row * C + col];
+    }
+    for (int i = threadIdx.x; i < K::A2; i += blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+        const int tq = rest % K::MT1, mt = rest / K::MT1;
+        const int row = 16 * mt + (lane & 15), col = 16 * tq + 4 * (lane >> 4) + e;
+        a2[i] = (row < nout) ? w1[row * HID + col] : 0.f;
+    }
+    for (int i = threadIdx.x; i < K::B0; i += blockDim.x) sb0[i] = b0[i];          // index = 16 mt + 4 g + r
+    for (int i = threadIdx.x; i < K::B1; i += blockDim.x) sb1[i] = (i < nout) ? b1[i] : 0.f;
+}
+
+__device__ __forceinline__ float softplus_fast(float x) {
+    // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); abs error ~1e-7, saturates like threshold=20.
+    const float e = __expf(-fabsf(x));
+    return fmaxf(x, 0.f) + __logf(1.0f + e);
+}
+
+// Gather this lane's NF features of one sample from one tri-plane (channels_last, channel stride 1).
+template <int C>
+__device__ __forceinline__ void gather_features(const float* __restrict__ pb, int64_t sH, int64_t sW,
+                                                const Tap2 (&t)[3], int g, float (&f)[C / 4]) {
+    constexpr int CPL = C / 16;
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+        const int ch = 4 * (g + 4 * ci);
+        const float4 a0 = gather_plane_cl(pb + ch, sH, sW, t[0]);
+        const float4 a1 = gather_plane_cl(pb + C + ch, sH, sW, t[1]);
+        const float4 a2 = gather_plane_cl(pb + 2 * C + ch, sH, sW, t[2]);
+        f[4 * ci + 0] = (a0.x + a1.x) + a2.x;
+        f[4 * ci + 1] = (a0.y + a1.y) + a2.y;
+        f[4 * ci + 2] = (a0.z + a1.z) + a2.z;
+        f[4 * ci + 3] = (a0.w + a1.w) + a2.w;
+    }
+}
+
+// Two-layer MLP on a 16-sample tile, transposed MFMA form.  out[mt][r] = feature 16 mt + 4 g + r of sample j.
+template <int C, int HID>
+__device__ __forceinline__ void mlp_tile(const float* __restrict__ s, const float (&f)[C / 4], f32x4 (&out)[2]) {
+    using K = RmCfg<C, HID>;
+    const int lane = lane_id();
+    const f32x4* a1 = reinterpret_cast<const f32x4*>(s);
+    const f32x4* a2 = reinterpret_cast<const f32x4*>(s + K::A1);
+    const f32x4* sb0 = reinterpret_cast<const f32x4*>(s + K::A1 + K::A2);
+    const f32x4* sb1 = reinterpret_cast<const f32x4*>(s + K::A1 + K::A2 + K::B0);
+    const int g = lane >> 4;
+    f32x4 h[K::MT1];
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt) h[mt] = sb0[mt * 4 + g];
+#pragma unroll
+    for (int ci = 0; ci < K::CPL; ++ci) {
+        f32x4 w[K::MT1];
+#pragma unroll
+        for (int mt = 0; mt < K::MT1; ++mt) w[mt] = a1[(mt * K::CPL + ci) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < K::MT1; ++mt)
+                h[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mt][e], f[4 * ci + e], h[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mt][r] = softplus_fast(h[mt][r]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) out[mt] = sb1[mt * 4 + g];
+#pragma unroll
+    for (int tq = 0; tq < K::MT1; ++tq) {
+        const f32x4 w0 = a2[(0 * K::MT1 + tq) * 64 + lane];
+        const f32x4 w1 = a2[(1 * K::MT1 + tq) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            out[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[e], h[tq][e], out[0], 0, 0, 0);
+            out[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], h[tq][e], out[1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float seg16_excl_prod(float v, float& total) {
+    // exclusive prefix product inside each aligned group of 16 lanes
+    const int j = lane_id() & 15;
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const float o = __shfl_up(incl, off, 16);
+        if (j >= off) incl *= o;
+    }
+    total = __shfl(incl, 15, 16);
+    const float prev = __shfl_up(incl, 1, 16);
+    return j == 0 ? 1.0f : prev;
+}
+
+template <int C, int HID>
+__global__ void __launch_bounds__(256, 2)
+render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
+    using K = RmCfg<C, HID>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_geo = lds;
+    float* s_tex = lds + K::MLP;
+    stage_mlp<C, HID>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
+    stage_mlp<C, HID>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
+    __syncthreads();
+
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int64_t total_rays = (int64_t)p.n * p.rays_per_img;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t ray_begin = (int64_t)blk * rays_per_block;
+    int64_t ray_end = ray_begin + rays_per_block;
+    if (ray_end > total_rays) ray_end = total_rays;
+    const int S = p.steps;
+    const int nch = p.feat_ch + p.seg_ch;
+
+    for (int64_t ray = ray_begin + wid; ray < ray_end; ray += 4) {
+        const int n = (int)(ray / p.rays_per_img);
+        const int r = (int)(ray - (int64_t)n * p.rays_per_img);
+        const float dx = p.rays_d_cam[r * 3 + 0], dy = p.rays_d_cam[r * 3 + 1], dz = p.rays_d_cam[r * 3 + 2];
+        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float* M = p.cam2world + n * 16;
+        const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
+        const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
+        const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
+        const float zstep = (S > 1) ? (p.z_lin[1] - p.z_lin[0]) : 0.f;
+        const float* jit = p.jitter ? p.jitter + ray * S : nullptr;
+        const float* sgn = p.sigma_noise ? p.sigma_noise + ray * S : nullptr;
+        const float* tex_b = p.tex_planes + n * p.tex_stride[0];
+        const float* geo_b = p.geo_planes + n * p.geo_stride[0];
+
+        float acc_t[8], acc_g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc_t[i] = 0.f; acc_g[i] = 0.f; }
+        float carry = 1.0f, wsum = 0.f, dsum = 0.f;
+
+        for (int s0 = 0; s0 < S; s0 += 16) {
+            const int s = s0 + j;
+            const bool live = s < S;
+            const int sc = live ? s : S - 1;
+            // --- sample position (camera space -> jitter -> world) ---
+            float z = p.z_lin[sc];
+            float px = __fmul_rn(dx, z), py = __fmul_rn(dy, z), pz = __fmul_rn(dz, z);
+            float znext = (sc + 1 < S) ? p.z_lin[sc + 1] : 0.f;
+            if (jit) {
+                const float off = __fmul_rn(__fsub_rn(jit[sc], 0.5f), zstep);
+                z = __fadd_rn(z, off);
+                px = __fadd_rn(px, __fmul_rn(off, dx));
+                py = __fadd_rn(py, __fmul_rn(off, dy));
+                pz = __fadd_rn(pz, __fmul_rn(off, dz));
+                if (sc + 1 < S) znext = __fadd_rn(znext, __fmul_rn(__fsub_rn(jit[sc + 1], 0.5f), zstep));
+            }
+            const float wx = fmaf(m00, px, fmaf(m01, py, fmaf(m02, pz, m03)));
+            const float wy = fmaf(m10, px, fmaf(m11, py, fmaf(m12, pz, m13)));
+            const float wz = fmaf(m20, px, fmaf(m21, py, fmaf(m22, pz, m23)));
+            // --- gathers ---
+            Tap2 t[3] = { make_tap(wx, wy, p.W, p.H), make_tap(wy, wz, p.W, p.H), make_tap(wx, wz, p.W, p.H) };
+            float fg[K::NF], ft[K::NF];
+            f32x4 og[2], ot[2];
+            gather_features<C>(geo_b, p.geo_stride[2], p.geo_stride[3], t, g, fg);
+            mlp_tile<C, HID>(s_geo, fg, og);
+            asm volatile("" ::: "memory");     // keep the second gather behind the first MLP (register budget)
+            gather_features<C>(tex_b, p.tex_stride[2], p.tex_stride[3], t, g, ft);
+            mlp_tile<C, HID>(s_tex, ft, ot);
+            // --- compositing weights ---
+            float sigma = __shfl(og[0][0], j);                    // feature 0 lives in lanes g = 0
+            if (sgn) sigma += sgn[sc];
+            const float dens = p.clamp_mode == 0 ? softplus_fast(sigma) : fmaxf(sigma, 0.f);
+            const float delta = (sc + 1 < S) ? (znext - z) * dnorm : 1e10f;
+            const float alpha = live ? 1.0f - __expf(-delta * dens) : 0.f;
+            const float fac = live ? (1.0f - alpha + 1e-10f) : 1.0f;
+            float tot;
+            const float excl = seg16_excl_prod(fac, tot);
+            const float w = alpha * (carry * excl);
+            carry *= tot;
+            wsum += w; dsum += w * z;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    acc_g[mt * 4 + rr] += w * og[mt][rr];
+                    acc_t[mt * 4 + rr] += w * ot[mt][rr];
+                }
+        }
+        // --- close the ray: reduce over the 16 samples held by lanes with equal g ---
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            wsum += __shfl_xor(wsum, off); dsum += __shfl_xor(dsum, off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc_g[i] += __shfl_xor(acc_g[i], off); acc_t[i] += __shfl_xor(acc_t[i], off); }
+        }
+        if (j == 0) {
+            // last_back needs the un-weighted features of the final sample; not supported in the fused
+            // kernel (host guards), white_back / max_depth are.
+            const float bg = p.white_back ? (1.0f - wsum) : 0.f;
+            float* of = p.out_feat + (int64_t)n * nch * p.rays_per_img + r;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int idx = 16 * mt + 4 * g + rr;
+                    if (idx < p.feat_ch) of[(int64_t)idx * p.rays_per_img] = acc_t[mt * 4 + rr] + bg;
+                    if (idx >= 1 && idx <= p.seg_ch) of[(int64_t)(p.feat_ch + idx - 1) * p.rays_per_img] = acc_g[mt * 4 + rr] + bg;
+                }
+            if (g == 0) {
+                if (p.out_depth) p.out_depth[ray] = dsum + ((p.max_depth != 0.f) ? (1.0f - wsum) * p.max_depth : 0.f);
+                if (p.out_wsum) p.out_wsum[ray] = wsum;
+            }
+        }
+    }
+}
+
+// sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
+template <int C, int HID>
+__global__ void __launch_bounds__(256, 2)
+sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_t m,
+                    float* __restrict__ out, float* __restrict__ out_sigma, int sigma_only, int64_t tiles_per_block) {
+    using K = RmCfg<C, HID>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_geo = lds;
+    float* s_tex = lds + K::MLP;
+    float* s_stage = lds + 2 * K::MLP;                 // [4 waves][16 samples][width] row staging
+    stage_mlp<C, HID>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
+    if (!sigma_only) stage_mlp<C, HID>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
+    __syncthreads();
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int width = p.feat_ch + p.seg_ch + 1;
+    float* stage = s_stage + wid * 16 * width;
+    const int64_t rows = (int64_t)p.n * m;
+    const int64_t ntiles = cdiv64(rows, 16);
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t tile_begin = (int64_t)blk * tiles_per_block;
+    int64_t tile_end = tile_begin + tiles_per_block;
+    if (tile_end > ntiles) tile_end = ntiles;
+    for (int64_t tile = tile_begin + wid; tile < tile_end; tile += 4) {
+        const int64_t row0 = tile * 16;
+        const int64_t row = row0 + j;
+        const bool live = row < rows;
+        const int64_t rc = live ? row : rows - 1;
+        const int n = (int)(rc / m);
+        const float wx = pts[rc * 3 + 0], wy = pts[rc * 3 + 1], wz = pts[rc * 3 + 2];
+        Tap2 t[3] = { make_tap(wx, wy, p.W, p.H), make_tap(wy, wz, p.W, p.H), make_tap(wx, wz, p.W, p.H) };
+        float fg[K::NF];
+        gather_features<C>(p.geo_planes + n * p.geo_stride[0], p.geo_stride[2], p.geo_stride[3], t, g, fg);
+        f32x4 og[2];
+        mlp_tile<C, HID>(s_geo, fg, og);
+        if (sigma_only) {
+            if (g == 0 && live) out_sigma[row] = og[0][0];
+            continue;
+        }
+        float ft[K::NF];
+        gather_features<C>(p.tex_planes + n * p.tex_stride[0], p.tex_stride[2], p.tex_stride[3], t, g, ft);
+        f32x4 ot[2];
+        mlp_tile<C, HID>(s_tex, ft, ot);
+        // stage the 16 x width row block, then write it out contiguously
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int idx = 16 * mt + 4 * g + rr;
+                if (idx < p.feat_ch) stage[j * width + idx] = ot[mt][rr];
+                if (idx >= 1 && idx <= p.seg_ch) stage[j * width + p.feat_ch + idx - 1] = og[mt][rr];
+                if (idx == 0) stage[j * width + width - 1] = og[mt][rr];
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const int64_t live_rows = (rows - row0 < 16) ? rows - row0 : 16;
+        const int64_t nel = live_rows * width;
+        float* dst = out + row0 * width;
+        for (int i = lane; i < nel; i += kWave) dst[i] = stage[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int C, int HID>
+static int launch_render(const ide3d_render_params& p, hipStream_t st) {
+    using K = RmCfg<C, HID>;
+    const size_t lds_bytes = (size_t)2 * K::MLP * sizeof(float);
+    const int64_t total_rays = (int64_t)p.n * p.rays_per_img;
+    int64_t nblk = kNumCU * 2;
+    int64_t rpb = cdiv64(cdiv64(total_rays, nblk), 4) * 4;
+    if (rpb < 4) rpb = 4;
+    nblk = cdiv64(total_rays, rpb);
+    auto kern = render_rays_kernel<C, HID>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, rpb);
+    IDE3D_CHECK_LAUNCH("render_rays");
+    return IDE3D_OK;
+}
+
+template <int C, int HID>
+static int launch_voxel(const ide3d_render_params& p, const float* pts, int64_t m, float* out, float* out_sigma,
+                        int sigma_only, hipStream_t st) {
+    using K = RmCfg<C, HID>;
+    const int width = p.feat_ch + p.seg_ch + 1;
+    const size_t lds_bytes = ((size_t)2 * K::MLP + (size_t)4 * 16 * width) * sizeof(float);
+    const int64_t ntiles = cdiv64((int64_t)p.n * m, 16);
+    int64_t nblk = kNumCU * 2;
+    int64_t tpb = cdiv64(cdiv64(ntiles, nblk), 4) * 4;
+    if (tpb < 4) tpb = 4;
+    nblk = cdiv64(ntiles, tpb);
+    auto kern = sample_voxel_kernel<C, HID>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, pts, m, out, out_sigma, sigma_only, tpb);
+    IDE3D_CHECK_LAUNCH("sample_voxel");
+    return IDE3D_OK;
+}
+
+static int check_render_params(const ide3d_render_params& p, const char* who, bool need_rays) {
+    IDE3D_CHECK_ARG(p.tex_planes && p.geo_planes, "%s: null tri-plane pointer", who);
+    IDE3D_CHECK_ARG(p.geo_w0 && p.geo_b0 && p.geo_w1 && p.geo_b1 && p.tex_w0 && p.tex_b0 && p.tex_w1 && p.tex_b1,
+                    "%s: null MLP weight pointer", who);
+    IDE3D_CHECK_ARG(p.n > 0 && p.C > 0 && p.H > 0 && p.W > 0, "%s: bad tri-plane shape", who);
+    IDE3D_CHECK_ARG(p.feat_ch >= 1 && p.feat_ch <= 32 && p.seg_ch >= 0 && p.seg_ch <= 31,
+                    "%s: feat_ch <= 32 and seg_ch <= 31 required", who);
+    if (need_rays) {
+        IDE3D_CHECK_ARG(p.rays_d_cam && p.z_lin && p.cam2world && p.out_feat, "%s: null ray / output pointer", who);
+        IDE3D_CHECK_ARG(p.rays_per_img > 0 && p.steps > 0, "%s: bad ray shape", who);
+        IDE3D_CHECK_ARG(p.clamp_mode == 0 || p.clamp_mode == 1, "%s: Need to choose clamp mode", who);
+    }
+    return IDE3D_OK;
+}
+
+static bool planes_fast(const ide3d_render_params& p) {
+    auto ok = [&](const float* base, const int64_t* s) {
+        return s[1] == 1 && (s[0] % 4 == 0) && (s[2] % 4 == 0) && (s[3] % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+    };
+    return ok(p.tex_planes, p.tex_stride) && ok(p.geo_planes, p.geo_stride);
+}
+
+}  // namespace ide3d
+
+extern "C" int ide3d_render_rays(const ide3d_render_params* pp, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(pp != nullptr, "render_rays: null params");
+    const ide3d_render_params& p = *pp;
+    int rc = check_render_params(p, "render_rays", true);
+    if (rc) return rc;
+    if (p.last_back) { set_error("render_rays: last_back is not fused; use the step-wise ops"); return IDE3D_ENOKERNEL; }
+    if (!planes_fast(p)) { set_error("render_rays: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (p.C == 32 && p.hidden == 64) return launch_render<32, 64>(p, st);
+    if (p.C == 16 && p.hidden == 32) return launch_render<16, 32>(p, st);
+    set_error("render_rays: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
+    return IDE3D_ENOKERNEL;
+}
+
+extern "C" int ide3d_sample_voxel(const ide3d_render_params* pp, const float* pts, int64_t m,
+                                  float* out, float* out_sigma, int sigma_only, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(pp != nullptr && pts != nullptr, "sample_voxel: null params");
+    const ide3d_render_params& p = *pp;
+    int rc = check_render_params(p, "sample_voxel", false);
+    if (rc) return rc;
+    IDE3D_CHECK_ARG(m >= 0, "sample_voxel: bad point count");
+    IDE3D_CHECK_ARG(sigma_only ? out_sigma != nullptr : out != nullptr, "sample_voxel: null output");
+    if (m == 0) return IDE3D_OK;
+    if (!planes_fast(p)) { set_error("sample_voxel: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, pts, m, out, out_sigma, sigma_only, st);
+    if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, pts, m, out, out_sigma, sigma_only, st);
+    set_error("sample_voxel: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
+    return IDE3D_ENOKERNEL;
+}

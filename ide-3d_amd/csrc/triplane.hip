@@ -1,0 +1,255 @@
+// triplane.hip — tri-plane bilinear feature gather (and its backward) for gfx950.
+//
+// Drop-in for `dnnlib.util.sample_from_triplane` (dnnlib/util.py:580-617): three
+// grid_sample(bilinear, zeros, align_corners=False) look-ups on the xy / yz / xz planes of a
+// [n, 3C, H, W] tensor, summed.  Plane p, axes (a -> W, b -> H): p0 = (x, y), p1 = (y, z),
+// p2 = (x, z).  Output row index = n * m + sample.
+//
+// MI355X mapping (fast path, channels_last planes, C % 4 == 0):
+//   * one bilinear tap = one contiguous C*4-byte read (128 B at C = 32) instead of C scattered
+//     4-byte reads: C/4 lanes cooperate on a sample with one global_load_dwordx4 each, so a
+//     wavefront retires 64/(C/4) samples per tap instruction and every fetched line is fully used;
+//   * consecutive samples are consecutive depth steps of one ray, so the 12 taps of a wave's
+//     samples hit neighbouring lines (L1/L2 reuse); workgroups take *contiguous* sample chunks and
+//     the chunk order is XCD-remapped so that neighbouring rays share one XCD's L2;
+//   * output rows are written as 16-byte vectors, fully coalesced (C*4 bytes per sample).
+// HBM roofline: (3*C*H*W + 3*m + C*m) * 4 bytes per image (planes + coords + output).
+//
+// Index math is bit-exact w.r.t. ATen grid_sampler_unnormalize (align_corners=False):
+//   u = ((c + 1) * size - 1) / 2 evaluated add, mul, sub, mul(0.5) in fp32 without contraction.
+#include "common.h"
+#include "triplane_tap.h"
+
+namespace ide3d {
+
+// Fast path: channels_last planes (stride of the channel axis == 1), C % 4 == 0, (C/4) | 64.
+template <int LPS>   // lanes per sample = C / 4
+__global__ void __launch_bounds__(256)
+triplane_sample_cl_kernel(const float* __restrict__ planes, int64_t sN, int64_t sH, int64_t sW,
+                          int C, int H, int W, const float* __restrict__ coords, int64_t m,
+                          int64_t rows, float* __restrict__ out, int64_t rows_per_block) {
+    constexpr int SPW = kWave / LPS;                     // samples per wave-iteration
+    constexpr int SPB = SPW * 4;                         // samples per workgroup-iteration (4 waves)
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row_begin = (int64_t)blk * rows_per_block;
+    int64_t row_end = row_begin + rows_per_block;
+    if (row_end > rows) row_end = rows;
+    const int sub = threadIdx.x / LPS;                   // sample slot inside the workgroup
+    const int cl = threadIdx.x % LPS;                    // 4-channel slice
+    for (int64_t row = row_begin + sub; row < row_end; row += SPB) {
+        const float* cp = coords + row * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const int64_t n = row / m;
+        const float* pb = planes + n * sN + cl * 4;
+        const Tap2 t0 = make_tap(cx, cy, W, H);
+        const Tap2 t1 = make_tap(cy, cz, W, H);
+        const Tap2 t2 = make_tap(cx, cz, W, H);
+        const float4 a0 = gather_plane_cl(pb, sH, sW, t0);
+        const float4 a1 = gather_plane_cl(pb + C, sH, sW, t1);
+        const float4 a2 = gather_plane_cl(pb + 2 * C, sH, sW, t2);
+        float4 r;
+        r.x = (a0.x + a1.x) + a2.x; r.y = (a0.y + a1.y) + a2.y;
+        r.z = (a0.z + a1.z) + a2.z; r.w = (a0.w + a1.w) + a2.w;
+        *reinterpret_cast<float4*>(out + row * C + cl * 4) = r;
+    }
+}
+
+// General strided path (NCHW or anything else): one lane per sample, loop over channels; the
+// output tile of the workgroup is transposed through LDS so that stores stay coalesced.
+__global__ void __launch_bounds__(256)
+triplane_sample_strided_kernel(const float* __restrict__ planes, int64_t sN, int64_t sC, int64_t sH, int64_t sW,
+                               int C, int H, int W, const float* __restrict__ coords, int64_t m,
+                               int64_t rows, float* __restrict__ out) {
+    __shared__ float s_out[256 * 33];                    // [sample][channel chunk of 32] padded
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t row0 = (int64_t)blockIdx.x * 256; row0 < rows; row0 += stride) {
+        const int64_t row = row0 + threadIdx.x;
+        const bool live = row < rows;
+        Tap2 t[3];
+        const float* pb = planes;
+        if (live) {
+            const float* cp = coords + row * 3;
+            const float cx = cp[0], cy = cp[1], cz = cp[2];
+            t[0] = make_tap(cx, cy, W, H); t[1] = make_tap(cy, cz, W, H); t[2] = make_tap(cx, cz, W, H);
+            pb = planes + (row / m) * sN;
+        }
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            const int cn = (C - c0 < 32) ? C - c0 : 32;
+            if (live) {
+                for (int c = 0; c < cn; ++c) {
+                    float tot[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const float* p00 = pb + ((int64_t)pl * C + c0 + c) * sC + t[pl].iy0 * sH + t[pl].ix0 * sW;
+                        float acc = 0.f;
+                        if (t[pl].mask & 1u) acc += p00[0] * t[pl].w00;
+                        if (t[pl].mask & 2u) acc += p00[sW] * t[pl].w01;
+                        if (t[pl].mask & 4u) acc += p00[sH] * t[pl].w10;
+                        if (t[pl].mask & 8u) acc += p00[sH + sW] * t[pl].w11;
+                        tot[pl] = acc;
+                    }
+                    s_out[threadIdx.x * 33 + c] = (tot[0] + tot[1]) + tot[2];
+                }
+            }
+            __syncthreads();
+            // Coalesced write-out: consecutive lanes -> consecutive channels of a sample.
+            for (int i = threadIdx.x; i < 256 * cn; i += 256) {
+                const int s = i / cn, c = i - s * cn;
+                if (row0 + s < rows) out[(row0 + s) * C + c0 + c] = s_out[s * 33 + c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+triplane_taps_kernel(int H, int W, const float* __restrict__ coords, int64_t rows, int32_t* __restrict__ taps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += stride) {
+        const float* cp = coords + row * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const Tap2 t0 = make_tap(cx, cy, W, H), t1 = make_tap(cy, cz, W, H), t2 = make_tap(cx, cz, W, H);
+        int32_t* o = taps + row * 9;
+        o[0] = t0.ix0; o[1] = t0.iy0; o[2] = (int)t0.mask;
+        o[3] = t1.ix0; o[4] = t1.iy0; o[5] = (int)t1.mask;
+        o[6] = t2.ix0; o[7] = t2.iy0; o[8] = (int)t2.mask;
+    }
+}
+
+// Backward: scatter-add of grad_out into grad_planes (+ optional coordinate gradients).
+__global__ void __launch_bounds__(256)
+triplane_backward_kernel(const float* __restrict__ grad_out, const float* __restrict__ planes,
+                         int64_t sN, int64_t sC, int64_t sH, int64_t sW,
+                         int C, int H, int W, const float* __restrict__ coords, int64_t m, int64_t rows,
+                         float* __restrict__ grad_planes, int64_t gN, int64_t gC, int64_t gH, int64_t gW,
+                         float* __restrict__ grad_coords) {
+    // One wave per sample-group: lanes run over channels so atomics on channels_last gradients coalesce.
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const float* cp = coords + row * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const int64_t n = row / m;
+        Tap2 t[3] = { make_tap(cx, cy, W, H), make_tap(cy, cz, W, H), make_tap(cx, cz, W, H) };
+        float gu[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};   // d/du, d/dv per plane (partial over lanes)
+        for (int c = lane; c < C; c += kWave) {
+            const float go = grad_out[row * C + c];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const int64_t ch = (int64_t)pl * C + c;
+                float* g00 = grad_planes + n * gN + ch * gC + t[pl].iy0 * gH + t[pl].ix0 * gW;
+                if (t[pl].mask & 1u) atomicAdd(g00, go * t[pl].w00);
+                if (t[pl].mask & 2u) atomicAdd(g00 + gW, go * t[pl].w01);
+                if (t[pl].mask & 4u) atomicAdd(g00 + gH, go * t[pl].w10);
+                if (t[pl].mask & 8u) atomicAdd(g00 + gH + gW, go * t[pl].w11);
+                if (grad_coords) {
+                    const float* p00 = planes + n * sN + ch * sC + t[pl].iy0 * sH + t[pl].ix0 * sW;
+                    const float v00 = (t[pl].mask & 1u) ? p00[0] : 0.f;
+                    const float v01 = (t[pl].mask & 2u) ? p00[sW] : 0.f;
+                    const float v10 = (t[pl].mask & 4u) ? p00[sH] : 0.f;
+                    const float v11 = (t[pl].mask & 8u) ? p00[sH + sW] : 0.f;
+                    // weights: w00 = ax*ay, w01 = bx*ay, w10 = ax*by, w11 = bx*by with ax = x1-u, bx = u-x0.
+                    const float u = unnormalize(pl == 1 ? cy : cx, W), v = unnormalize(pl == 0 ? cy : cz, H);
+                    const float bx = u - floorf(u), ax = 1.f - bx, by = v - floorf(v), ay = 1.f - by;
+                    gu[pl] += go * ((v01 - v00) * ay + (v11 - v10) * by);
+                    gv[pl] += go * ((v10 - v00) * ax + (v11 - v01) * bx);
+                }
+            }
+        }
+        if (grad_coords) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                for (int off = kWave / 2; off > 0; off >>= 1) {
+                    gu[pl] += __shfl_xor(gu[pl], off);
+                    gv[pl] += __shfl_xor(gv[pl], off);
+                }
+            if (lane == 0) {
+                // du/dc = size / 2 (align_corners=False).  x feeds planes 0,2 (u); y feeds plane 0 (v) and
+                // plane 1 (u); z feeds planes 1,2 (v).
+                const float hx = 0.5f * W, hy = 0.5f * H;
+                grad_coords[row * 3 + 0] = (gu[0] + gu[2]) * hx;
+                grad_coords[row * 3 + 1] = gv[0] * hy + gu[1] * hx;
+                grad_coords[row * 3 + 2] = (gv[1] + gv[2]) * hy;
+            }
+        }
+    }
+}
+
+template <int LPS>
+static void launch_cl(const float* planes, const int64_t* s, int n, int C, int H, int W,
+                      const float* coords, int64_t m, float* out, hipStream_t st) {
+    const int64_t rows = (int64_t)n * m;
+    constexpr int SPB = (kWave / LPS) * 4;
+    // ~8 workgroups per CU; contiguous chunks, multiple of the per-iteration sample count.
+    int64_t nblk = kNumCU * 8;
+    int64_t rpb = cdiv64(cdiv64(rows, nblk), SPB) * SPB;
+    if (rpb < SPB) rpb = SPB;
+    nblk = cdiv64(rows, rpb);
+    hipLaunchKernelGGL((triplane_sample_cl_kernel<LPS>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       planes, s[0], s[2], s[3], C, H, W, coords, m, rows, out, rpb);
+}
+
+}  // namespace ide3d
+
+extern "C" int ide3d_triplane_sample(const float* planes, const int64_t plane_stride[4],
+                                     int32_t n, int32_t C, int32_t H, int32_t W,
+                                     const float* coords, int64_t m, float* out, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(planes && coords && out && plane_stride, "triplane_sample: null pointer");
+    IDE3D_CHECK_ARG(n > 0 && C > 0 && H > 0 && W > 0 && m >= 0, "triplane_sample: bad shape");
+    if (m == 0) return IDE3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t* s = plane_stride;
+    const bool cl = (s[1] == 1) && (C % 4 == 0) && (s[0] % 4 == 0) && (s[2] % 4 == 0) && (s[3] % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(planes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const int lps = C / 4;
+    if (cl && lps >= 1 && lps <= 64 && (64 % lps) == 0) {
+        switch (lps) {
+        case 1:  launch_cl<1>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 2:  launch_cl<2>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 4:  launch_cl<4>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 8:  launch_cl<8>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 16: launch_cl<16>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 32: launch_cl<32>(planes, s, n, C, H, W, coords, m, out, st); break;
+        case 64: launch_cl<64>(planes, s, n, C, H, W, coords, m, out, st); break;
+        }
+    } else {
+        const int64_t rows = (int64_t)n * m;
+        hipLaunchKernelGGL(triplane_sample_strided_kernel, dim3(stream_grid(rows, 256)), dim3(256), 0, st,
+                           planes, s[0], s[1], s[2], s[3], C, H, W, coords, m, rows, out);
+    }
+    IDE3D_CHECK_LAUNCH("triplane_sample");
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_triplane_taps(int32_t H, int32_t W, const float* coords, int64_t rows,
+                                   int32_t* taps, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(coords && taps && H > 0 && W > 0 && rows >= 0, "triplane_taps: bad argument");
+    if (rows == 0) return IDE3D_OK;
+    hipLaunchKernelGGL(triplane_taps_kernel, dim3(stream_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       H, W, coords, rows, taps);
+    IDE3D_CHECK_LAUNCH("triplane_taps");
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_triplane_sample_backward(const float* grad_out, const float* planes,
+                                              const int64_t plane_stride[4],
+                                              int32_t n, int32_t C, int32_t H, int32_t W,
+                                              const float* coords, int64_t m,
+                                              float* grad_planes, const int64_t grad_plane_stride[4],
+                                              float* grad_coords, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(grad_out && planes && coords && grad_planes && plane_stride && grad_plane_stride,
+                    "triplane_sample_backward: null pointer");
+    IDE3D_CHECK_ARG(n > 0 && C > 0 && H > 0 && W > 0 && m >= 0, "triplane_sample_backward: bad shape");
+    if (m == 0) return IDE3D_OK;
+    const int64_t rows = (int64_t)n * m;
+    const int64_t* s = plane_stride; const int64_t* g = grad_plane_stride;
+    hipLaunchKernelGGL(triplane_backward_kernel, dim3(stream_grid(rows * kWave, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, planes, s[0], s[1], s[2], s[3], C, H, W, coords, m, rows,
+                       grad_planes, g[0], g[1], g[2], g[3], grad_coords);
+    IDE3D_CHECK_LAUNCH("triplane_sample_backward");
+    return IDE3D_OK;
+}

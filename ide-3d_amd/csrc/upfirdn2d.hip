@@ -1,0 +1,266 @@
+// upfirdn2d.hip — pad -> zero-upsample -> 2-D FIR -> decimate, for gfx950.
+//
+// Semantics follow the reference op (torch_utils/ops/upfirdn2d.py:118, upfirdn2d.cpp:16):
+//   out[oy, ox] = gain * sum_{ky,kx} U[oy*dy + ky - pad_y0, ox*dx + kx - pad_x0] * g[ky, kx]
+// where U is the zero-upsampled input (U[iy*uy, ix*ux] = x[iy, ix], 0 elsewhere / outside) and
+// g = f flipped in both axes (true convolution) unless `flip` is set.
+//
+// Two kernels:
+//  * upfirdn2d_tile<...>: LDS-tiled polyphase kernel for the shapes on the IDE-3D render path
+//    (4x4 [1,3,3,1] filter, up in {1,2}, down in {1,2}) and w-contiguous (NCHW) tensors.  A
+//    256-thread workgroup stages the input window of its output tile in LDS (zero-filled
+//    outside the image), every lane then owns a register micro-tile and walks only the taps
+//    that hit non-zero samples of its polyphase component.  Filter taps are read once through
+//    uniform (scalar) loads.  HBM traffic = input + output, each touched once.
+//  * upfirdn2d_generic: one output element per lane, any (up, down, filter, strides, dtype);
+//    lanes run along the unit-stride axis (w for NCHW, c for channels_last) so global
+//    accesses stay coalesced.
+#include "common.h"
+#include <type_traits>
+
+namespace ide3d {
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel
+// ------------------------------------------------------------------------------------------------
+
+template <class T>
+__global__ void __launch_bounds__(256)
+upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, int c_fastest) {
+    using M = typename Elem<T>::math_t;
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const int64_t total = (int64_t)p.n * p.c * p.out_h * p.out_w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int ox, oy, c, n;
+        int64_t r = idx;
+        if (c_fastest) {
+            c = (int)(r % p.c); r /= p.c;
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); r /= p.out_h;
+            n = (int)r;
+        } else {
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); r /= p.out_h;
+            c = (int)(r % p.c); r /= p.c;
+            n = (int)r;
+        }
+        // First tap whose upsampled coordinate lands on a real sample, per axis.
+        const int X0 = ox * p.down_x - p.pad_x0;           // upsampled x of tap kx = 0
+        const int Y0 = oy * p.down_y - p.pad_y0;
+        int kx0 = ((-X0) % p.up_x + p.up_x) % p.up_x;
+        int ky0 = ((-Y0) % p.up_y + p.up_y) % p.up_y;
+        const T* xp = x + n * p.x_stride[0] + c * p.x_stride[1];
+        M acc = 0;
+        for (int ky = ky0; ky < p.f_h; ky += p.up_y) {
+            const int iy = (Y0 + ky) / p.up_y;              // exact: Y0 + ky is a multiple of up_y
+            if (iy < 0 || iy >= p.in_h) continue;
+            const int fy = p.flip ? ky : p.f_h - 1 - ky;
+            for (int kx = kx0; kx < p.f_w; kx += p.up_x) {
+                const int ix = (X0 + kx) / p.up_x;
+                if (ix < 0 || ix >= p.in_w) continue;
+                const int fx = p.flip ? kx : p.f_w - 1 - kx;
+                acc += Elem<T>::ld(xp + iy * p.x_stride[2] + ix * p.x_stride[3]) *
+                       (M)p.f[fy * p.f_stride[0] + fx * p.f_stride[1]];
+            }
+        }
+        Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3],
+                    acc * (M)p.gain);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile kernel (NCHW, compile-time up/down/filter)
+// ------------------------------------------------------------------------------------------------
+
+// Polyphase bookkeeping for one axis.  U = up factor, D = down factor (U == 1 || D == 1), F = taps.
+template <int U, int D, int F>
+struct Axis {
+    static constexpr int NT = (F + U - 1) / U;                  // max taps per phase
+    // With U > 1 (D == 1) outputs are grouped in cells of U consecutive "shifted" outputs
+    // o' = o - pad0 = q*U + r.  Phase r uses filter taps k = first(r) + t*U and inputs q + off(r) + t.
+    static constexpr int first(int r) { return (U - r) % U; }
+    static constexpr int ntaps(int r) { return first(r) < F ? (F - first(r) + U - 1) / U : 0; }
+    static constexpr int off(int r) { return r == 0 ? 0 : 1; }
+    // Input window (elements) needed by C consecutive cells.
+    static constexpr int window(int C) { return U > 1 ? C + NT : (C - 1) * D + F; }
+    // Input step between consecutive cells.
+    static constexpr int step = (U > 1) ? 1 : D;
+};
+
+template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>
+__global__ void __launch_bounds__(256)
+upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, int tiles_x, int tiles_y) {
+    using M = typename Elem<T>::math_t;
+    using AX = Axis<UX, DX, FW>;
+    using AY = Axis<UY, DY, FH>;
+    constexpr int TX = 32, TY = 8;                              // thread grid inside the workgroup
+    constexpr int TCX = TX * CX, TCY = TY * CY;                 // cells per tile
+    constexpr int LW = ((AX::window(TCX) + 3) & ~3) + 4;        // LDS tile width (padded, see bank note)
+    constexpr int LH = AY::window(TCY);
+    constexpr int WX = AX::window(CX), WY = AY::window(CY);     // per-thread register window
+
+    __shared__ __attribute__((aligned(16))) M s_in[LH * LW];
+
+    // Flipped + gained taps through uniform loads (stay in SGPRs / constant VGPRs).
+    M g[FH][FW];
+#pragma unroll
+    for (int ky = 0; ky < FH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < FW; ++kx) {
+            const int fy = p.flip ? ky : FH - 1 - ky;
+            const int fx = p.flip ? kx : FW - 1 - kx;
+            g[ky][kx] = (M)p.f[fy * p.f_stride[0] + fx * p.f_stride[1]] * (M)p.gain;
+        }
+
+    // Tile decomposition: blockIdx.x -> (plane, tile_y, tile_x) with XCD-aware remap so that
+    // vertically adjacent tiles of one plane (which share halo rows) sit in the same XCD's L2.
+    const int nblocks = gridDim.x;
+    int bid = xcd_remap(blockIdx.x, nblocks);
+    const int tx_i = bid % tiles_x; bid /= tiles_x;
+    const int ty_i = bid % tiles_y; bid /= tiles_y;
+    const int plane = bid;                                      // n * C + c
+    const int n = plane / p.c, c = plane % p.c;
+
+    // Cell-space origin.  For U > 1: q_min = floor(-pad0 / U) is the cell holding output 0.
+    const int qx_min = (UX > 1) ? floordiv(-p.pad_x0, UX) : 0;
+    const int qy_min = (UY > 1) ? floordiv(-p.pad_y0, UY) : 0;
+    const int qx0 = qx_min + tx_i * TCX;
+    const int qy0 = qy_min + ty_i * TCY;
+    // Input coordinate of LDS element (0, 0).
+    const int in_x0 = (UX > 1) ? qx0 : qx0 * DX - p.pad_x0;
+    const int in_y0 = (UY > 1) ? qy0 : qy0 * DY - p.pad_y0;
+
+    const T* __restrict__ xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int iy = in_y0 + ly, ix = in_x0 + lx;
+        M v = 0;
+        if (lx < AX::window(TCX) && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
+            v = Elem<T>::ld(xp + iy * p.x_stride[2] + ix);
+        s_in[i] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    // Register window.
+    M win[WY][WX];
+    const int lx0 = tx * CX * AX::step, ly0 = ty * CY * AY::step;
+#pragma unroll
+    for (int wy = 0; wy < WY; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < WX; ++wx)
+            win[wy][wx] = s_in[(ly0 + wy) * LW + lx0 + wx];
+
+    T* __restrict__ yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
+#pragma unroll
+    for (int cy = 0; cy < CY; ++cy)
+#pragma unroll
+        for (int ry = 0; ry < UY; ++ry) {
+            const int qy = qy0 + ty * CY + cy;
+            const int oy = (UY > 1) ? qy * UY + ry + p.pad_y0 : qy;
+            if (oy < 0 || oy >= p.out_h) continue;
+            M row[CX * UX];
+#pragma unroll
+            for (int cx = 0; cx < CX; ++cx)
+#pragma unroll
+                for (int rx = 0; rx < UX; ++rx) {
+                    M acc = 0;
+#pragma unroll
+                    for (int ty_ = 0; ty_ < AY::ntaps(ry); ++ty_)
+#pragma unroll
+                        for (int tx_ = 0; tx_ < AX::ntaps(rx); ++tx_) {
+                            const int wy = (UY > 1) ? cy + AY::off(ry) + ty_ : cy * DY + ty_;
+                            const int wx = (UX > 1) ? cx + AX::off(rx) + tx_ : cx * DX + tx_;
+                            acc += win[wy][wx] * g[AY::first(ry) + ty_ * UY][AX::first(rx) + tx_ * UX];
+                        }
+                    row[cx * UX + rx] = acc;
+                }
+            // Store CX*UX consecutive outputs.
+            const int qx = qx0 + tx * CX;
+            const int ox0 = (UX > 1) ? qx * UX + p.pad_x0 : qx;
+            T* yr = yp + oy * p.y_stride[2];
+            constexpr int NO = CX * UX;
+            if constexpr (sizeof(T) == 4 && NO == 4) {
+                if (ox0 >= 0 && ox0 + NO <= p.out_w && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
+                    float4 v4 = make_float4(row[0], row[1], row[2], row[3]);
+                    *reinterpret_cast<float4*>(yr + ox0) = v4;
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int ox = ox0 + j;
+                if (ox >= 0 && ox < p.out_w) Elem<T>::st(yr + ox, row[j]);
+            }
+        }
+}
+
+template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>
+static int launch_tile(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+    constexpr int TCX = 32 * CX, TCY = 8 * CY;
+    // Number of cells needed to cover the outputs on each axis.
+    auto cells = [](int out, int pad0, int U) {
+        if (U == 1) return out;
+        const int q_min = floordiv(-pad0, U);
+        const int q_max = floordiv(out - 1 - pad0, U);
+        return q_max - q_min + 1;
+    };
+    const int tiles_x = cdiv(cells(p.out_w, p.pad_x0, UX), TCX);
+    const int tiles_y = cdiv(cells(p.out_h, p.pad_y0, UY), TCY);
+    const int64_t nblocks = (int64_t)tiles_x * tiles_y * p.n * p.c;
+    if (nblocks > 0x7fffffff) { set_error("upfirdn2d: grid too large"); return IDE3D_EINVAL; }
+    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, CX, CY>), dim3((unsigned)nblocks),
+                       dim3(256), 0, st, p, tiles_x, tiles_y);
+    IDE3D_CHECK_LAUNCH("upfirdn2d_tile");
+    return IDE3D_OK;
+}
+
+template <class T>
+static int launch_generic(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.n * p.c * p.out_h * p.out_w;
+    const int c_fastest = (p.y_stride[1] == 1 && p.c > 1) ? 1 : 0;
+    hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3(stream_grid(total, 256)), dim3(256), 0, st, p, c_fastest);
+    IDE3D_CHECK_LAUNCH("upfirdn2d_generic");
+    return IDE3D_OK;
+}
+
+template <class T>
+static int dispatch(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+    const bool w_contig = (p.x_stride[3] == 1 && p.y_stride[3] == 1);
+    if constexpr (!std::is_same<T, double>::value) {
+        if (w_contig && p.f_w == 4 && p.f_h == 4) {
+            if (p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1)
+                return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 2>(p, st);
+            if (p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1)
+                return launch_tile<T, 2, 2, 1, 1, 4, 4, 2, 2>(p, st);
+            if (p.up_x == 1 && p.up_y == 1 && p.down_x == 2 && p.down_y == 2)
+                return launch_tile<T, 1, 1, 2, 2, 4, 4, 4, 2>(p, st);
+        }
+    }
+    return launch_generic<T>(p, st);
+}
+
+}  // namespace ide3d
+
+extern "C" int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* pp, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(pp != nullptr, "upfirdn2d: null params");
+    const ide3d_upfirdn2d_params& p = *pp;
+    IDE3D_CHECK_ARG(p.x && p.f && p.y, "upfirdn2d: null tensor pointer");
+    IDE3D_CHECK_ARG(p.n > 0 && p.c > 0 && p.in_h > 0 && p.in_w > 0, "upfirdn2d: x is empty");
+    IDE3D_CHECK_ARG(p.f_h >= 1 && p.f_w >= 1, "upfirdn2d: f is empty");
+    IDE3D_CHECK_ARG(p.up_x >= 1 && p.up_y >= 1, "upfirdn2d: upsampling factor must be at least 1");
+    IDE3D_CHECK_ARG(p.down_x >= 1 && p.down_y >= 1, "upfirdn2d: downsampling factor must be at least 1");
+    IDE3D_CHECK_ARG(p.out_h >= 1 && p.out_w >= 1, "upfirdn2d: output must be at least 1x1");
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.dtype) {
+    case IDE3D_F32:  return dispatch<float>(p, st);
+    case IDE3D_F16:  return dispatch<__half>(p, st);
+    case IDE3D_BF16: return dispatch<__hip_bfloat16>(p, st);
+    case IDE3D_F64:  return dispatch<double>(p, st);
+    }
+    set_error("upfirdn2d: unsupported dtype code %d", p.dtype);
+    return IDE3D_EINVAL;
+}

@@ -1,0 +1,166 @@
+"""`dnnlib.util` pieces the render path needs: EasyDict, by-name construction and the tri-plane /
+grid feature samplers (reference dnnlib/util.py:46, :242-310, :561-617).
+
+`sample_from_triplane` is the drop-in point of the HIP gather kernel (`csrc/triplane.hip`): float32
+device tensors take the kernel, everything else (CPU, other dtypes) takes the PyTorch definition.
+"""
+
+import importlib
+import sys
+import types
+from typing import Any, Tuple
+
+import torch
+
+from torch_utils import custom_ops
+from torch_utils.ops import grid_sample_gradfix
+
+
+class EasyDict(dict):
+    """dict with attribute access."""
+
+    def __getattr__(self, name: str) -> Any:
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        self[name] = value
+
+    def __delattr__(self, name: str) -> None:
+        del self[name]
+
+
+# ---- by-name object construction (reference util.py:242-310) -------------------------------------
+
+def get_module_from_obj_name(obj_name: str) -> Tuple[types.ModuleType, str]:
+    """Split 'pkg.mod.Obj.attr' into (imported module, 'Obj.attr'), trying the longest module path first."""
+    parts = obj_name.split('.')
+    last_err = None
+    for i in range(len(parts), 0, -1):
+        module_name, local_name = '.'.join(parts[:i]), '.'.join(parts[i:])
+        try:
+            module = importlib.import_module(module_name)
+        except ImportError as e:
+            if not str(e).startswith("No module named '" + module_name.split('.')[0]) and module_name in str(e):
+                last_err = e
+            continue
+        try:
+            get_obj_from_module(module, local_name)
+            return module, local_name
+        except AttributeError as e:
+            last_err = e
+    raise ImportError(f'cannot resolve "{obj_name}"') from last_err
+
+
+def get_obj_from_module(module: types.ModuleType, obj_name: str) -> Any:
+    obj = module
+    if obj_name:
+        for part in obj_name.split('.'):
+            obj = getattr(obj, part)
+    return obj
+
+
+def get_obj_by_name(name: str) -> Any:
+    module, local = get_module_from_obj_name(name)
+    return get_obj_from_module(module, local)
+
+
+def call_func_by_name(*args, func_name: str = None, **kwargs) -> Any:
+    assert func_name is not None
+    fn = get_obj_by_name(func_name)
+    assert callable(fn)
+    return fn(*args, **kwargs)
+
+
+def construct_class_by_name(*args, class_name: str = None, **kwargs) -> Any:
+    return call_func_by_name(*args, func_name=class_name, **kwargs)
+
+
+# ---- feature samplers ---------------------------------------------------------------------------------
+
+_triplane_plugin = None
+
+
+def _triplane_init():
+    global _triplane_plugin
+    if _triplane_plugin is None:
+        _triplane_plugin = custom_ops.get_plugin(module_name='triplane_plugin', sources=['triplane.hip'], headers=['triplane_tap.h'])
+    return True
+
+
+class _TriplaneSampleHip(torch.autograd.Function):
+    """HIP tri-plane gather with gradients w.r.t. planes and coordinates."""
+
+    @staticmethod
+    def forward(ctx, coordinates, grid):
+        if grid.stride(1) != 1:
+            # NCHW planes: one channels_last copy so that every bilinear tap is a contiguous C*4-byte read.
+            grid = grid.contiguous(memory_format=torch.channels_last)
+        out = _triplane_plugin.sample(grid, coordinates)
+        ctx.save_for_backward(coordinates, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coordinates, grid = ctx.saved_tensors
+        grad_planes, grad_coords = _triplane_plugin.sample_backward(grad_out, grid, coordinates, ctx.needs_input_grad[0])
+        return (grad_coords if ctx.needs_input_grad[0] else None), (grad_planes if ctx.needs_input_grad[1] else None)
+
+
+def sample_from_3dgrid(coordinates, grid):
+    """Trilinear look-up: coordinates [B, M, 3], grid [1 or B, C, H, W, D] -> [B, M, C]
+    (align_corners=True, zeros padding — reference util.py:561-577)."""
+    coordinates = coordinates.float()
+    grid = grid.float()
+    b, m, d = coordinates.shape
+    feats = torch.nn.functional.grid_sample(grid.expand(b, -1, -1, -1, -1), coordinates.reshape(b, 1, 1, -1, d),
+                                            mode='bilinear', padding_mode='zeros', align_corners=True)
+    n, c, h, w, dd = feats.shape
+    return feats.permute(0, 4, 3, 2, 1).reshape(n, h * w * dd, c)
+
+
+def sample_from_2dgrid(coordinates, grid):
+    """Bilinear look-up: coordinates [B, M, 2], grid [B, C, H, W] -> [B*M, C] (reference util.py:603-617)."""
+    b = grid.shape[0]
+    feats = grid_sample_gradfix.grid_sample(grid, coordinates.reshape(b, -1, 1, 2))
+    n, c, h, w = feats.shape
+    return feats.permute(0, 3, 2, 1).reshape(n * h * w, c)
+
+
+def _sample_from_triplane_ref(coordinates, grid):
+    n, c3, h, w = grid.shape
+    planes = grid.reshape(n, 3, c3 // 3, h, w)
+    xy = sample_from_2dgrid(coordinates[..., [0, 1]], planes[:, 0])
+    yz = sample_from_2dgrid(coordinates[..., [1, 2]], planes[:, 1])
+    xz = sample_from_2dgrid(coordinates[..., [0, 2]], planes[:, 2])
+    return xy + yz + xz
+
+
+def sample_from_triplane(coordinates, grid, impl='cuda'):
+    """Sum of the xy / yz / xz plane look-ups: coordinates [B, M, 3], grid [B, 3*C, H, W] -> [B*M, C]
+    (reference util.py:580-599; planes are square in every caller)."""
+    assert impl in ['ref', 'cuda']
+    use_hip = (impl == 'cuda' and grid.device.type == 'cuda' and grid.dtype == torch.float32
+               and coordinates.dtype == torch.float32 and grid.shape[2] == grid.shape[3]
+               and not grid_sample_gradfix.enabled)
+    if use_hip and _triplane_init():
+        return _TriplaneSampleHip.apply(coordinates, grid)
+    return _sample_from_triplane_ref(coordinates, grid)
+
+
+def layout_grid(img, grid_w=None, grid_h=1, float_to_uint8=True, chw_to_hwc=True, to_numpy=True):
+    """Tile a batch [B, C, H, W] into one [grid_h*H, grid_w*W, C] uint8 image (reference util.py:632-646)."""
+    b, c, h, w = img.shape
+    if grid_w is None:
+        grid_w = b // grid_h
+    assert b == grid_w * grid_h
+    if float_to_uint8:
+        img = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8)
+    img = img.reshape(grid_h, grid_w, c, h, w).permute(2, 0, 3, 1, 4).reshape(c, grid_h * h, grid_w * w)
+    if chw_to_hwc:
+        img = img.permute(1, 2, 0)
+    if to_numpy:
+        img = img.cpu().numpy()
+    return img

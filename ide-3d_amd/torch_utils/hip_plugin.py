@@ -1,0 +1,588 @@
+"""ctypes binding of libide3d_hip.so (C ABI: include/ide3d_hip.h).
+
+This is the host half of the drop-in boundary.  The reference loads one pybind11 module per op
+through `torch_utils.custom_ops.get_plugin` (custom_ops.py:59) and calls `_plugin.<fn>(tensors...)`
+(bias_act.py:150, upfirdn2d.py:242, filtered_lrelu.py:217,228).  Here the same call shapes are kept:
+every `*Plugin` class below exposes functions with the reference plugin's argument order, validates
+like the reference's TORCH_CHECKs, allocates outputs with torch (memory format preserved) and hands
+raw device pointers + the current HIP stream to the C ABI.  PyTorch is only plumbing (device memory,
+streams); all arithmetic happens in the hand-written HIP kernels.
+
+There is deliberately NO fallback in this file: if the shared library is missing, was built for a
+different arch, or a launch fails, a RuntimeError is raised.
+"""
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
+_ABI_VERSION = 1
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+_lock = threading.Lock()
+_lib = None
+
+# number of successful C-ABI launches per entry point (tests assert the native path really ran)
+CALLS = {}
+
+
+def lib_path():
+    env = os.environ.get(_LIB_ENV)
+    if env:
+        return env
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(here), 'lib', 'libide3d_hip.so')
+
+
+class _UpfirdnParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('f', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('dtype', ctypes.c_int32),
+        ('n', ctypes.c_int32), ('c', ctypes.c_int32), ('in_h', ctypes.c_int32), ('in_w', ctypes.c_int32),
+        ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32),
+        ('x_stride', ctypes.c_int64 * 4), ('y_stride', ctypes.c_int64 * 4),
+        ('f_h', ctypes.c_int32), ('f_w', ctypes.c_int32),
+        ('f_stride', ctypes.c_int64 * 2),
+        ('up_x', ctypes.c_int32), ('up_y', ctypes.c_int32), ('down_x', ctypes.c_int32), ('down_y', ctypes.c_int32),
+        ('pad_x0', ctypes.c_int32), ('pad_y0', ctypes.c_int32),
+        ('flip', ctypes.c_int32), ('gain', ctypes.c_float),
+    ]
+
+
+class _FlreluParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('b', ctypes.c_void_p), ('s', ctypes.c_void_p),
+        ('fu', ctypes.c_void_p), ('fd', ctypes.c_void_p),
+        ('dtype', ctypes.c_int32),
+        ('n', ctypes.c_int32), ('c', ctypes.c_int32), ('in_h', ctypes.c_int32), ('in_w', ctypes.c_int32),
+        ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32),
+        ('x_stride', ctypes.c_int64 * 4), ('y_stride', ctypes.c_int64 * 4),
+        ('fu_w', ctypes.c_int32), ('fu_h', ctypes.c_int32), ('fd_w', ctypes.c_int32), ('fd_h', ctypes.c_int32),
+        ('fu_stride', ctypes.c_int64 * 2), ('fd_stride', ctypes.c_int64 * 2),
+        ('up', ctypes.c_int32), ('down', ctypes.c_int32),
+        ('pad_x0', ctypes.c_int32), ('pad_y0', ctypes.c_int32),
+        ('s_w_bytes', ctypes.c_int32), ('s_h', ctypes.c_int32),
+        ('s_ofs_x', ctypes.c_int32), ('s_ofs_y', ctypes.c_int32),
+        ('sw_limit', ctypes.c_int32), ('sign_mode', ctypes.c_int32),
+        ('flip', ctypes.c_int32),
+        ('gain', ctypes.c_float), ('slope', ctypes.c_float), ('clamp', ctypes.c_float),
+    ]
+
+
+class _RenderParams(ctypes.Structure):
+    _fields_ = [
+        ('rays_d_cam', ctypes.c_void_p), ('z_lin', ctypes.c_void_p), ('cam2world', ctypes.c_void_p),
+        ('jitter', ctypes.c_void_p), ('sigma_noise', ctypes.c_void_p),
+        ('tex_planes', ctypes.c_void_p), ('geo_planes', ctypes.c_void_p),
+        ('tex_stride', ctypes.c_int64 * 4), ('geo_stride', ctypes.c_int64 * 4),
+        ('geo_w0', ctypes.c_void_p), ('geo_b0', ctypes.c_void_p), ('geo_w1', ctypes.c_void_p), ('geo_b1', ctypes.c_void_p),
+        ('tex_w0', ctypes.c_void_p), ('tex_b0', ctypes.c_void_p), ('tex_w1', ctypes.c_void_p), ('tex_b1', ctypes.c_void_p),
+        ('n', ctypes.c_int32), ('rays_per_img', ctypes.c_int32), ('steps', ctypes.c_int32),
+        ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+        ('hidden', ctypes.c_int32), ('feat_ch', ctypes.c_int32), ('seg_ch', ctypes.c_int32),
+        ('clamp_mode', ctypes.c_int32), ('last_back', ctypes.c_int32), ('white_back', ctypes.c_int32),
+        ('max_depth', ctypes.c_float),
+        ('out_feat', ctypes.c_void_p), ('out_depth', ctypes.c_void_p), ('out_wsum', ctypes.c_void_p),
+    ]
+
+
+class _ModconvParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('styles', ctypes.c_void_p), ('dcoefs', ctypes.c_void_p),
+        ('noise', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('n', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout', ctypes.c_int32),
+        ('h', ctypes.c_int32), ('w_', ctypes.c_int32), ('k', ctypes.c_int32),
+        ('noise_strength', ctypes.c_float),
+        ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
+    ]
+
+
+def _hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (there must be exactly one)."""
+    paths = set()
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'libamdhip64' in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return paths
+
+
+def load():
+    """dlopen libide3d_hip.so once and declare the prototypes.  Raises RuntimeError if unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.isfile(path):
+            raise RuntimeError(
+                f'libide3d_hip.so not found at {path}. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C ide-3d_amd/csrc`, or point ${_LIB_ENV} at it. There is no CPU/eager fallback for CUDA tensors.')
+        # torch ships its own libamdhip64.so (soname libamdhip64.so.7); make sure it is the one already mapped
+        # so that our kernels share torch's HIP runtime, streams and allocations.
+        torch.cuda.is_available()
+        try:
+            lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        except OSError as e:
+            raise RuntimeError(f'failed to load {path}: {e}') from e
+        rts = _hip_runtimes_mapped()
+        if len(rts) > 1:
+            raise RuntimeError(f'two HIP runtimes mapped in one process ({sorted(rts)}); import torch before loading the plugin')
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        lib.ide3d_last_error.restype = ctypes.c_char_p
+        lib.ide3d_last_error.argtypes = []
+        lib.ide3d_abi_version.restype = ctypes.c_int
+        lib.ide3d_build_arch.restype = ctypes.c_char_p
+        if lib.ide3d_abi_version() != _ABI_VERSION:
+            raise RuntimeError(f'{path}: ABI version {lib.ide3d_abi_version()} != expected {_ABI_VERSION}; rebuild')
+        protos = {
+            'ide3d_bias_act': [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32, f32, f32, i64, i64, i64, vp],
+            'ide3d_upfirdn2d': [ctypes.POINTER(_UpfirdnParams), vp],
+            'ide3d_filtered_lrelu': [ctypes.POINTER(_FlreluParams), vp],
+            'ide3d_filtered_lrelu_act': [vp, vp, ctypes.c_int, i32, i32, i32, i32, ctypes.POINTER(i64 * 4),
+                                         i32, i32, i32, i32, f32, f32, f32, ctypes.c_int, vp],
+            'ide3d_triplane_sample': [vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, i64, vp, vp],
+            'ide3d_triplane_taps': [i32, i32, vp, i64, vp, vp],
+            'ide3d_triplane_sample_backward': [vp, vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, i64,
+                                               vp, ctypes.POINTER(i64 * 4), vp, vp],
+            'ide3d_composite': [vp, vp, vp, vp, i64, i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32,
+                                ctypes.c_int, vp, vp, vp, vp],
+            'ide3d_render_rays': [ctypes.POINTER(_RenderParams), vp],
+            'ide3d_sample_voxel': [ctypes.POINTER(_RenderParams), vp, i64, vp, vp, ctypes.c_int, vp],
+            'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
+            'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+        }
+        for name, argtypes in protos.items():
+            fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+            fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+        _lib = lib
+        return _lib
+
+
+EXPORTED_SYMBOLS = (
+    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d',
+    'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_taps',
+    'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
+    'ide3d_modconv2d', 'ide3d_frame_u8',
+)
+
+
+def _check(rc, what):
+    if rc == 0:
+        CALLS[what] = CALLS.get(what, 0) + 1
+    if rc != 0:
+        msg = load().ide3d_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed (code {rc}): {msg}')
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if (t is not None and t.numel() > 0) else ctypes.c_void_p(0)
+
+
+def _i64x4(vals):
+    return (ctypes.c_int64 * 4)(*[int(v) for v in vals])
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.ndim == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+# ------------------------------------------------------------------------------------------------
+# bias_act_plugin
+# ------------------------------------------------------------------------------------------------
+
+class BiasActPlugin:
+    """`bias_act_plugin` of the reference (bias_act.cpp:32-97)."""
+
+    @staticmethod
+    def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
+        _require(x.is_cuda, 'x must reside on CUDA device')
+        for name, t in (('b', b), ('xref', xref), ('yref', yref), ('dy', dy)):
+            if t.numel():
+                _require(t.device == x.device, f'{name} must reside on the same device as x')
+                _require(t.dtype == x.dtype, f'{name} must have the same dtype as x')
+        _require(x.dtype in _DTYPE_CODE, 'x must be float16, bfloat16, float32 or float64')
+        _require(b.numel() == 0 or (b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]),
+                 'b must be a vector matching dimension `dim` of x')
+        _require(b.numel() == 0 or b.is_contiguous(), 'b must be contiguous')
+        for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
+            _require(t.numel() == 0 or (t.shape == x.shape and t.stride() == x.stride()),
+                     f'{name} must have the same shape and layout as x')
+        _require(grad >= 0, 'grad must be non-negative')
+        _require(_dense(x) or x.numel() == 0 or x.is_non_overlapping_and_dense(), 'x must be non-overlapping and dense')
+        y = torch.empty_like(x)
+        _require(y.stride() == x.stride(), 'internal: output layout differs from input layout')
+        if x.numel() == 0:
+            return y
+        step_b = x.stride(dim) if b.numel() else 1
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_bias_act(_ptr(x), _ptr(b), _ptr(xref), _ptr(yref), _ptr(dy), _ptr(y),
+                                       _DTYPE_CODE[x.dtype], int(grad), int(act), float(alpha), float(gain), float(clamp),
+                                       x.numel(), max(b.numel(), 1), int(step_b), _stream(x))
+        _check(rc, 'bias_act')
+        return y
+
+
+# ------------------------------------------------------------------------------------------------
+# upfirdn2d_plugin
+# ------------------------------------------------------------------------------------------------
+
+class Upfirdn2dPlugin:
+    """`upfirdn2d_plugin` of the reference (upfirdn2d.cpp:16-105)."""
+
+    @staticmethod
+    def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+        _require(x.is_cuda, 'x must reside on CUDA device')
+        _require(f.device == x.device, 'f must reside on the same device as x')
+        _require(f.dtype == torch.float32, 'f must be float32')
+        _require(x.dtype in _DTYPE_CODE, 'x must be float16, bfloat16, float32 or float64')
+        _require(x.numel() > 0, 'x has zero size')
+        _require(f.numel() > 0, 'f has zero size')
+        _require(x.ndim == 4, 'x must be rank 4')
+        _require(f.ndim == 2, 'f must be rank 2')
+        _require(f.shape[0] >= 1 and f.shape[1] >= 1, 'f must be at least 1x1')
+        _require(upx >= 1 and upy >= 1, 'upsampling factor must be at least 1')
+        _require(downx >= 1 and downy >= 1, 'downsampling factor must be at least 1')
+        n, c, ih, iw = x.shape
+        ow = (iw * upx + padx0 + padx1 - f.shape[1] + downx) // downx
+        oh = (ih * upy + pady0 + pady1 - f.shape[0] + downy) // downy
+        _require(ow >= 1 and oh >= 1, 'output must be at least 1x1')
+        cl = x.ndim == 4 and x.stride(1) == 1 and c > 1
+        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        p = _UpfirdnParams()
+        p.x, p.f, p.y = x.data_ptr(), f.data_ptr(), y.data_ptr()
+        p.dtype = _DTYPE_CODE[x.dtype]
+        p.n, p.c, p.in_h, p.in_w, p.out_h, p.out_w = n, c, ih, iw, oh, ow
+        p.x_stride = _i64x4(x.stride())
+        p.y_stride = _i64x4(y.stride())
+        p.f_h, p.f_w = f.shape
+        p.f_stride = (ctypes.c_int64 * 2)(f.stride(0), f.stride(1))
+        p.up_x, p.up_y, p.down_x, p.down_y = upx, upy, downx, downy
+        p.pad_x0, p.pad_y0 = padx0, pady0
+        p.flip, p.gain = int(bool(flip)), float(gain)
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_upfirdn2d(ctypes.byref(p), _stream(x))
+        _check(rc, 'upfirdn2d')
+        return y
+
+
+# ------------------------------------------------------------------------------------------------
+# filtered_lrelu_plugin
+# ------------------------------------------------------------------------------------------------
+
+class FilteredLReluPlugin:
+    """`filtered_lrelu_plugin` of the reference (filtered_lrelu.cpp:16-298)."""
+
+    @staticmethod
+    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, write_signs):
+        _require(x.is_cuda, 'x must reside on CUDA device')
+        _require(fu.device == x.device and fd.device == x.device and b.device == x.device,
+                 'all input tensors must reside on the same device')
+        _require(fu.dtype == torch.float32 and fd.dtype == torch.float32, 'fu and fd must be float32')
+        _require(b.dtype == x.dtype, 'x and b must have the same dtype')
+        _require(x.dtype in (torch.float16, torch.float32, torch.bfloat16), 'x and b must be float16, bfloat16 or float32')
+        _require(x.ndim == 4, 'x must be rank 4')
+        _require(x.numel() > 0, 'x is empty')
+        _require(fu.ndim in (1, 2) and fd.ndim in (1, 2), 'fu and fd must be rank 1 or 2')
+        _require(fu.numel() > 0, 'fu is empty')
+        _require(fd.numel() > 0, 'fd is empty')
+        _require(b.ndim == 1 and b.shape[0] == x.shape[1], 'b must be a vector with the same number of channels as x')
+        _require(up >= 1 and down >= 1, 'up and down must be at least 1')
+        n, c, xh, xw = x.shape
+        fut_w, fut_h = fu.shape[-1] - 1, fu.shape[0] - 1
+        fdt_w, fdt_h = fd.shape[-1] - 1, fd.shape[0] - 1
+        cw = xw * up + (px0 + px1) - fut_w
+        ch = xh * up + (py0 + py1) - fut_h
+        _require(cw > fdt_w and ch > fdt_h, 'upsampled buffer must be at least the size of downsampling filter')
+        yw = (cw - fdt_w + (down - 1)) // down
+        yh = (ch - fdt_h + (down - 1)) // down
+        _require(yw > 0 and yh > 0, 'output must be at least 1x1')
+        read_signs = si.numel() > 0
+        so = torch.empty([0], dtype=torch.uint8, device=x.device)
+        s = si
+        sw_active = 0
+        if write_signs:
+            sw_active = yw * down - (down - 1) + fdt_w
+            sh = yh * down - (down - 1) + fdt_h
+            sw = (sw_active + 15) & ~15
+            s = so = torch.empty([n, c, sh, sw >> 2], dtype=torch.uint8, device=x.device)
+        elif read_signs:
+            sw_active = s.shape[3] << 2
+        if read_signs or write_signs:
+            _require(s.is_contiguous(), 'signs must be contiguous')
+            _require(s.dtype == torch.uint8, 'signs must be uint8')
+            _require(s.device == x.device, 'signs must reside on the same device as x')
+            _require(s.ndim == 4, 'signs must be rank 4')
+            _require(s.shape[0] == n and s.shape[1] == c, 'signs must have same batch & channels as x')
+        cl = x.stride(1) == 1 and c > 1
+        y = torch.empty([n, c, yh, yw], dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        p = _FlreluParams()
+        p.x, p.y, p.b = x.data_ptr(), y.data_ptr(), b.contiguous().data_ptr()
+        p.s = s.data_ptr() if (read_signs or write_signs) else 0
+        p.fu, p.fd = fu.data_ptr(), fd.data_ptr()
+        p.dtype = _DTYPE_CODE[x.dtype]
+        p.n, p.c, p.in_h, p.in_w, p.out_h, p.out_w = n, c, xh, xw, yh, yw
+        p.x_stride, p.y_stride = _i64x4(x.stride()), _i64x4(y.stride())
+        p.fu_w, p.fu_h = fu.shape[-1], (fu.shape[0] if fu.ndim == 2 else 0)
+        p.fd_w, p.fd_h = fd.shape[-1], (fd.shape[0] if fd.ndim == 2 else 0)
+        p.fu_stride = (ctypes.c_int64 * 2)(fu.stride(0) if fu.ndim == 2 else 0, fu.stride(-1))
+        p.fd_stride = (ctypes.c_int64 * 2)(fd.stride(0) if fd.ndim == 2 else 0, fd.stride(-1))
+        p.up, p.down, p.pad_x0, p.pad_y0 = up, down, px0, py0
+        p.s_w_bytes, p.s_h = (s.shape[3], s.shape[2]) if (read_signs or write_signs) else (0, 0)
+        p.s_ofs_x, p.s_ofs_y = sx, sy
+        p.sw_limit = (sw_active + 3) >> 2
+        p.sign_mode = 1 if write_signs else (2 if read_signs else 0)
+        p.flip = int(bool(flip_filters))
+        p.gain, p.slope, p.clamp = float(gain), float(slope), float(min(clamp, 3.0e38))
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_filtered_lrelu(ctypes.byref(p), _stream(x))
+        if rc == -2:     # IDE3D_ENOKERNEL: same contract as the reference's return_code = -1
+            return torch.empty([0], device=x.device), torch.empty([0], device=x.device), -1
+        _check(rc, 'filtered_lrelu')
+        return y, so, 0
+
+    @staticmethod
+    def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
+        _require(x.is_cuda, 'x must reside on CUDA device')
+        _require(x.ndim == 4, 'x must be rank 4')
+        _require(x.numel() > 0, 'x is empty')
+        _require(x.dtype in _DTYPE_CODE, 'x must be float16, bfloat16, float32 or float64')
+        n, c, h, w = x.shape
+        read_signs = si.numel() > 0
+        so = torch.empty([0], dtype=torch.uint8, device=x.device)
+        s = si
+        if write_signs:
+            sw = (w + 15) & ~15
+            s = so = torch.empty([n, c, h, sw >> 2], dtype=torch.uint8, device=x.device)
+        if read_signs or write_signs:
+            _require(s.is_contiguous(), 'signs must be contiguous')
+            _require(s.dtype == torch.uint8, 'signs must be uint8')
+            _require(s.device == x.device, 'signs must reside on the same device as x')
+            _require(s.ndim == 4, 'signs must be rank 4')
+            _require(s.shape[0] == n and s.shape[1] == c, 'signs must have same batch & channels as x')
+        s_w, s_h = ((s.shape[3] << 2), s.shape[2]) if (read_signs or write_signs) else (0, 0)
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_filtered_lrelu_act(
+                _ptr(x), _ptr(s) if (read_signs or write_signs) else ctypes.c_void_p(0), _DTYPE_CODE[x.dtype],
+                n, c, h, w, ctypes.byref(_i64x4(x.stride())), s_w, s_h, sx, sy,
+                float(gain), float(slope), float(min(clamp, 3.0e38)),
+                1 if write_signs else (2 if read_signs else 0), _stream(x))
+        _check(rc, 'filtered_lrelu_act_')
+        return so
+
+
+# ------------------------------------------------------------------------------------------------
+# tri-plane gather / compositing / fused renderer / modulated conv / frame conversion
+# ------------------------------------------------------------------------------------------------
+
+class TriplanePlugin:
+    @staticmethod
+    def sample(planes, coords):
+        """planes [n, 3C, H, W] float32 (any strides), coords [n, m, 3] float32 -> [n*m, C]."""
+        _require(planes.is_cuda and coords.device == planes.device, 'planes and coords must be on the same CUDA device')
+        _require(planes.dtype == torch.float32 and coords.dtype == torch.float32, 'planes and coords must be float32')
+        _require(planes.ndim == 4 and planes.shape[1] % 3 == 0, 'planes must be [n, 3*C, H, W]')
+        _require(coords.ndim == 3 and coords.shape[2] == 3 and coords.shape[0] == planes.shape[0], 'coords must be [n, m, 3]')
+        n, c3, H, W = planes.shape
+        C = c3 // 3
+        coords = coords.contiguous()
+        m = coords.shape[1]
+        out = torch.empty([n * m, C], dtype=torch.float32, device=planes.device)
+        if m == 0:
+            return out
+        with torch.cuda.device(planes.device):
+            rc = load().ide3d_triplane_sample(_ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
+                                              _ptr(coords), m, _ptr(out), _stream(planes))
+        _check(rc, 'triplane_sample')
+        return out
+
+    @staticmethod
+    def taps(H, W, coords):
+        coords = coords.contiguous().reshape(-1, 3)
+        _require(coords.is_cuda and coords.dtype == torch.float32, 'coords must be float32 on a CUDA device')
+        taps = torch.empty([coords.shape[0], 3, 3], dtype=torch.int32, device=coords.device)
+        if coords.shape[0]:
+            with torch.cuda.device(coords.device):
+                rc = load().ide3d_triplane_taps(H, W, _ptr(coords), coords.shape[0], _ptr(taps), _stream(coords))
+            _check(rc, 'triplane_taps')
+        return taps
+
+    @staticmethod
+    def sample_backward(grad_out, planes, coords, need_coord_grad):
+        n, c3, H, W = planes.shape
+        C = c3 // 3
+        coords = coords.contiguous()
+        grad_out = grad_out.contiguous()
+        m = coords.shape[1]
+        grad_planes = torch.zeros_like(planes)
+        grad_coords = torch.zeros_like(coords) if need_coord_grad else None
+        if m:
+            with torch.cuda.device(planes.device):
+                rc = load().ide3d_triplane_sample_backward(
+                    _ptr(grad_out), _ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
+                    _ptr(coords), m, _ptr(grad_planes), ctypes.byref(_i64x4(grad_planes.stride())),
+                    _ptr(grad_coords), _stream(planes))
+            _check(rc, 'triplane_sample_backward')
+        return grad_planes, grad_coords
+
+
+class VolumeRenderPlugin:
+    @staticmethod
+    def composite(rgb_sigma, z_vals, dir_norm, noise, clamp_mode, last_back, white_back, max_depth, fill_mode,
+                  want_weights=True):
+        """rgb_sigma [rays, steps, ch+1], z_vals [rays, steps], dir_norm [rays], noise [rays, steps] | None."""
+        _require(rgb_sigma.is_cuda and rgb_sigma.dtype == torch.float32, 'rgb_sigma must be float32 on a CUDA device')
+        rays, steps, row = rgb_sigma.shape
+        ch = row - 1
+        rgb_sigma, z_vals, dir_norm = rgb_sigma.contiguous(), z_vals.contiguous(), dir_norm.contiguous()
+        if noise is not None:
+            noise = noise.contiguous()
+        dev = rgb_sigma.device
+        rgb = torch.empty([rays, ch], dtype=torch.float32, device=dev)
+        depth = torch.empty([rays], dtype=torch.float32, device=dev)
+        weights = torch.empty([rays, steps], dtype=torch.float32, device=dev) if want_weights else None
+        with torch.cuda.device(dev):
+            rc = load().ide3d_composite(_ptr(rgb_sigma), _ptr(z_vals), _ptr(dir_norm), _ptr(noise), rays, steps, ch,
+                                        int(clamp_mode), int(bool(last_back)), int(bool(white_back)), float(max_depth or 0.0),
+                                        int(fill_mode), _ptr(rgb), _ptr(depth), _ptr(weights), _stream(rgb_sigma))
+        _check(rc, 'composite')
+        return rgb, depth, weights
+
+    @staticmethod
+    def _fill_render_params(p, tex_planes, geo_planes, mlp):
+        p.tex_planes, p.geo_planes = tex_planes.data_ptr(), geo_planes.data_ptr()
+        p.tex_stride, p.geo_stride = _i64x4(tex_planes.stride()), _i64x4(geo_planes.stride())
+        for k in ('geo_w0', 'geo_b0', 'geo_w1', 'geo_b1', 'tex_w0', 'tex_b0', 'tex_w1', 'tex_b1'):
+            t = mlp[k]
+            _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), f'{k} must be contiguous float32 on GPU')
+            setattr(p, k, t.data_ptr())
+        n, c3, H, W = tex_planes.shape
+        _require(geo_planes.shape == tex_planes.shape, 'texture and geometry tri-planes must have the same shape')
+        p.n, p.C, p.H, p.W = n, c3 // 3, H, W
+        p.hidden = mlp['geo_w0'].shape[0]
+        p.seg_ch = mlp['geo_w1'].shape[0] - 1
+        p.feat_ch = mlp['tex_w1'].shape[0]
+
+    @staticmethod
+    def render_rays(rays_d_cam, z_lin, cam2world, jitter, sigma_noise, tex_planes, geo_planes, mlp,
+                    clamp_mode, last_back, white_back, max_depth):
+        dev = tex_planes.device
+        for t in (rays_d_cam, z_lin, cam2world, tex_planes, geo_planes):
+            _require(t.is_cuda and t.dtype == torch.float32, 'render_rays: float32 CUDA tensors required')
+        rays_d_cam, z_lin = rays_d_cam.contiguous(), z_lin.contiguous()
+        cam2world = cam2world.reshape(-1, 16).contiguous()
+        p = _RenderParams()
+        VolumeRenderPlugin._fill_render_params(p, tex_planes, geo_planes, mlp)
+        p.rays_d_cam, p.z_lin, p.cam2world = rays_d_cam.data_ptr(), z_lin.data_ptr(), cam2world.data_ptr()
+        p.rays_per_img, p.steps = rays_d_cam.shape[0], z_lin.shape[0]
+        keep = [rays_d_cam, z_lin, cam2world]
+        if jitter is not None:
+            jitter = jitter.contiguous(); keep.append(jitter); p.jitter = jitter.data_ptr()
+        if sigma_noise is not None:
+            sigma_noise = sigma_noise.contiguous(); keep.append(sigma_noise); p.sigma_noise = sigma_noise.data_ptr()
+        p.clamp_mode, p.last_back, p.white_back = int(clamp_mode), int(bool(last_back)), int(bool(white_back))
+        p.max_depth = float(max_depth or 0.0)
+        n, R = p.n, p.rays_per_img
+        feat = torch.empty([n, p.feat_ch + p.seg_ch, R], dtype=torch.float32, device=dev)
+        depth = torch.empty([n, R], dtype=torch.float32, device=dev)
+        wsum = torch.empty([n, R], dtype=torch.float32, device=dev)
+        p.out_feat, p.out_depth, p.out_wsum = feat.data_ptr(), depth.data_ptr(), wsum.data_ptr()
+        with torch.cuda.device(dev):
+            rc = load().ide3d_render_rays(ctypes.byref(p), _stream(tex_planes))
+        if rc == -2:        # IDE3D_ENOKERNEL: configuration not covered by the fused kernel
+            return None
+        _check(rc, 'render_rays')
+        return feat, depth, wsum
+
+    @staticmethod
+    def sample_voxel(tex_planes, geo_planes, mlp, pts, sigma_only=False):
+        dev = tex_planes.device
+        pts = pts.contiguous()
+        _require(pts.is_cuda and pts.dtype == torch.float32 and pts.ndim == 3 and pts.shape[2] == 3, 'pts must be [n, m, 3] float32')
+        p = _RenderParams()
+        VolumeRenderPlugin._fill_render_params(p, tex_planes, geo_planes, mlp)
+        n, m = pts.shape[0], pts.shape[1]
+        _require(n == p.n, 'pts batch must match the tri-plane batch')
+        width = p.feat_ch + p.seg_ch + 1
+        out = None if sigma_only else torch.empty([n * m, width], dtype=torch.float32, device=dev)
+        sig = torch.empty([n * m], dtype=torch.float32, device=dev) if sigma_only else None
+        if m:
+            with torch.cuda.device(dev):
+                rc = load().ide3d_sample_voxel(ctypes.byref(p), _ptr(pts), m, _ptr(out), _ptr(sig), int(sigma_only), _stream(pts))
+            if rc == -2:
+                return None
+            _check(rc, 'sample_voxel')
+        return sig if sigma_only else out
+
+
+class ModconvPlugin:
+    @staticmethod
+    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp):
+        for t in (x, w, styles):
+            _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'modconv2d: contiguous float32 CUDA tensors required')
+        n, cin, h, wd = x.shape
+        cout, cin2, k, k2 = w.shape
+        _require(cin == cin2 and k == k2 and k in (1, 3), 'modconv2d: weight must be [cout, cin, k, k] with k in {1, 3}')
+        y = torch.empty([n, cout, h, wd], dtype=torch.float32, device=x.device)
+        p = _ModconvParams()
+        p.x, p.w, p.styles, p.y = x.data_ptr(), w.data_ptr(), styles.data_ptr(), y.data_ptr()
+        keep = []
+        for name, t in (('dcoefs', dcoefs), ('noise', noise), ('bias', bias)):
+            if t is not None:
+                t = t.contiguous(); keep.append(t)
+                _require(t.is_cuda and t.dtype == torch.float32, f'modconv2d: {name} must be float32 on GPU')
+                setattr(p, name, t.data_ptr())
+        p.n, p.cin, p.cout, p.h, p.w_, p.k = n, cin, cout, h, wd, k
+        p.noise_strength = float(noise_strength)
+        p.act, p.alpha, p.gain, p.clamp = int(act), float(alpha), float(gain), float(clamp)
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_modconv2d(ctypes.byref(p), _stream(x))
+        _check(rc, 'modconv2d')
+        return y
+
+
+class FramePlugin:
+    @staticmethod
+    def frame_u8(img, seg, palette):
+        img, seg = img.contiguous(), seg.contiguous()
+        _require(img.is_cuda and img.dtype == torch.float32 and seg.dtype == torch.float32, 'frame_u8: float32 CUDA tensors required')
+        n, _, H, W = img.shape
+        classes = seg.shape[1]
+        _require(palette.dtype == torch.uint8 and palette.shape == (classes, 3) and palette.is_cuda, 'palette must be uint8 [classes, 3] on GPU')
+        out = torch.empty([n, H, 2 * W, 3], dtype=torch.uint8, device=img.device)
+        with torch.cuda.device(img.device):
+            rc = load().ide3d_frame_u8(_ptr(img), _ptr(seg), _ptr(palette.contiguous()), n, classes, H, W, _ptr(out), _stream(img))
+        _check(rc, 'frame_u8')
+        return out
+
+
+PLUGINS = {
+    'bias_act_plugin': BiasActPlugin,
+    'upfirdn2d_plugin': Upfirdn2dPlugin,
+    'filtered_lrelu_plugin': FilteredLReluPlugin,
+    'triplane_plugin': TriplanePlugin,
+    'volume_render_plugin': VolumeRenderPlugin,
+    'modconv_plugin': ModconvPlugin,
+    'frame_plugin': FramePlugin,
+}

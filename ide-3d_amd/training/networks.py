@@ -1,0 +1,437 @@
+"""StyleGAN2 building blocks of the IDE-3D tri-plane generator.
+
+The released IDE-3D generator lives only inside its pickle; the blocks it is made of
+correspond to the StyleNeRF-derived `inversion/networks.py` of the reference: `modulated_conv2d` (:55),
+`FullyConnectedLayer` (:136), `Conv2dLayer` (:170), `MappingNetwork` (:246), `SynthesisLayer` (:330),
+`ToRGBLayer` (:670) and the dual-path `SegSynthesisBlock` (:966).  This module re-states those blocks
+(2-D mode, default up-sampling, 'skip' / 'orig' architectures) with identical parameter and buffer
+names, so state dicts are interchangeable with the reference's blocks, and `training.networks.*` is
+the module path the reference's blocks look up by default (`layer_name`, networks.py:765,1016).
+
+MI355X specifics: on device tensors in inference (no autograd graph) a stride-1 modulated convolution
+and its epilogue (noise, bias, leaky ReLU, gain, clamp) are ONE fp32-MFMA implicit-GEMM launch
+(`csrc/modconv.hip`); up-sampling layers run the reference's transposed-convolution + FIR strategy
+with the FIR, the demodulation/noise and the bias-activation on HIP kernels.  With autograd the blocks
+evaluate the same mathematics through differentiable ops.
+"""
+
+import numpy as np
+import torch
+
+from dnnlib import util
+from torch_utils import custom_ops
+from torch_utils import misc
+from torch_utils import persistence
+from torch_utils.ops import bias_act
+from torch_utils.ops import conv2d_resample
+from torch_utils.ops import fma
+from torch_utils.ops import upfirdn2d
+
+_modconv_plugin = None
+
+# Route stride-1 modulated convolutions on device tensors through csrc/modconv.hip (inference only).
+use_hip_modconv = True
+
+
+def _modconv_init():
+    global _modconv_plugin
+    if _modconv_plugin is None:
+        _modconv_plugin = custom_ops.get_plugin(module_name='modconv_plugin', sources=['modconv.hip'])
+    return True
+
+
+def _inference_on_gpu(*tensors):
+    x = tensors[0]
+    if x.device.type != 'cuda' or x.dtype != torch.float32:
+        return False
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return False
+    return True
+
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def _demod_coefs(weight, styles):
+    """d[n, o] = rsqrt(sum_{i,k} (w[o,i,k] * s[n,i])^2 + 1e-8) without materialising per-sample weights."""
+    wsq = weight.square().sum(dim=[2, 3])                 # [O, I]
+    return (styles.square() @ wsq.t() + 1e-8).rsqrt()     # [N, O]
+
+
+@misc.profiled_function
+def modulated_conv2d(
+    x,                          # [N, Cin, H, W]
+    weight,                     # [Cout, Cin, kh, kw]
+    styles,                     # [N, Cin]
+    noise           = None,     # tensor broadcastable to the output, added after the convolution
+    up              = 1,
+    down            = 1,
+    padding         = 0,
+    resample_filter = None,     # from upfirdn2d.setup_filter()
+    demodulate      = True,
+    flip_weight     = True,     # True = correlation (torch conv2d)
+    fused_modconv   = True,     # one grouped conv over per-sample weights (reference :116-130) vs scale-conv-scale
+    mode            = '2d',
+    **unused,
+):
+    """Modulated convolution (reference inversion/networks.py:55-130)."""
+    assert mode == '2d', 'only 2-D modulated convolutions are part of the render path'
+    batch_size = x.shape[0]
+    cout, cin, kh, kw = weight.shape
+
+    # ---- MI355X inference path: one implicit-GEMM launch for stride-1 k in {1, 3} ----
+    if (use_hip_modconv and up == 1 and down == 1 and kh == kw and kh in (1, 3) and padding == kh // 2 and flip_weight
+            and _inference_on_gpu(x, weight, styles) and _modconv_init()):
+        dcoefs = _demod_coefs(weight, styles) if demodulate else None
+        y = _modconv_plugin.modconv2d(x.contiguous(), weight.contiguous(), styles.contiguous(), dcoefs,
+                                      None, 0.0, None, 1, 0.0, 1.0, -1.0)
+        if noise is not None:
+            y = y.add_(noise)
+        return y
+
+    if x.dtype == torch.float16 and demodulate:   # pre-normalise to stay inside fp16 range (reference :76-80)
+        weight = weight * (1 / np.sqrt(cin * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+
+    if not fused_modconv:
+        dcoefs = _demod_coefs(weight, styles) if demodulate else None
+        x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
+        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+                                            padding=padding, flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
+        elif demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1)
+        elif noise is not None:
+            x = x.add_(noise.to(x.dtype))
+        return x
+
+    # fused form: per-sample weights, one grouped convolution
+    w = weight.unsqueeze(0) * styles.reshape(batch_size, 1, -1, 1, 1)           # [N, O, I, k, k]
+    if demodulate:
+        dcoefs = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()                 # [N, O]
+        w = w * dcoefs.reshape(batch_size, -1, 1, 1, 1)
+    with misc.suppress_tracer_warnings():
+        batch_size = int(batch_size)
+    x = x.reshape(1, -1, *x.shape[2:])
+    w = w.reshape(-1, cin, kh, kw)
+    x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+                                        groups=batch_size, flip_weight=flip_weight)
+    x = x.reshape(batch_size, -1, *x.shape[2:])
+    if noise is not None:
+        x = x.add_(noise)
+    return x
+
+
+def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bias, act, gain, clamp):
+    """Stride-1 modulated conv + noise + bias + activation in one HIP launch (inference only).
+    Returns None when the fused kernel does not apply."""
+    cout, cin, kh, kw = weight.shape
+    if not (use_hip_modconv and kh == kw and kh in (1, 3) and act in ('linear', 'lrelu')
+            and _inference_on_gpu(x, weight, styles, bias) and _modconv_init()):
+        return None
+    spec = bias_act.activation_funcs[act]
+    dcoefs = _demod_coefs(weight, styles) if demodulate else None
+    return _modconv_plugin.modconv2d(
+        x.contiguous(), weight.contiguous(), styles.contiguous(), dcoefs, noise2d, noise_strength, bias,
+        spec.cuda_idx, spec.def_alpha, gain, -1.0 if clamp is None else clamp)
+
+
+@persistence.persistent_class
+class FullyConnectedLayer(torch.nn.Module):
+    """Equalised-learning-rate dense layer (reference networks.py:136-165)."""
+
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def effective(self, dtype=torch.float32):
+        """(weight, bias) with the runtime gains folded in."""
+        w = self.weight.to(dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        return w, b
+
+    def forward(self, x):
+        w, b = self.effective(x.dtype)
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        x = x.matmul(w.t())
+        return bias_act.bias_act(x, b, act=self.activation)
+
+
+@persistence.persistent_class
+class Conv2dLayer(torch.nn.Module):
+    """Plain (un-modulated) convolution with optional resampling (reference networks.py:170-226)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True, **unused):
+        super().__init__()
+        self.activation = activation
+        self.up = up
+        self.down = down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
+
+
+@persistence.persistent_class
+class MappingNetwork(torch.nn.Module):
+    """z (+ camera label c) -> ws (reference networks.py:246-325)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, **unused):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.num_ws, self.num_layers, self.w_avg_beta = num_ws, num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        widths = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(widths[idx], widths[idx + 1], activation=activation,
+                                                          lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z=None, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False, styles=None,
+                **unused_kwargs):
+        if styles is not None:
+            return styles
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+@persistence.persistent_class
+class SynthesisLayer(torch.nn.Module):
+    """Modulated 3x3 conv (+ optional x2 up-sampling) + noise + bias + lrelu (reference networks.py:330-514,
+    `upsample_mode='default'`, 2-D)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
+                 activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, **unused_kwargs):
+        super().__init__()
+        self.resolution = resolution
+        self.up = up
+        self.use_noise = use_noise
+        self.activation = activation
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, input_noise=None, **unused_kwargs):
+        assert noise_mode in ['random', 'const', 'none']
+        styles = self.affine(w)
+        if styles.size(0) < x.size(0):
+            assert x.size(0) % styles.size(0) == 0
+            styles = styles.repeat_interleave(x.size(0) // styles.size(0), dim=0)
+
+        noise = None
+        const_noise = False
+        if self.use_noise:
+            if input_noise is not None:
+                noise = input_noise * self.noise_strength
+            elif noise_mode == 'random':
+                noise = torch.randn([x.shape[0], 1, self.up * x.shape[2], self.up * x.shape[3]], device=x.device) * self.noise_strength
+            elif noise_mode == 'const':
+                const_noise = self.noise_const.shape[-1] >= self.up * x.shape[3]
+                noise = self.noise_const * self.noise_strength
+                if not const_noise:
+                    noise = noise.repeat(1, self.up * x.shape[3] // noise.shape[-1])
+
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+
+        if self.up == 1:
+            # single-launch path: conv + const/absent noise + bias + activation
+            if noise is None or (const_noise and input_noise is None and noise.shape == x.shape[2:]):
+                # `noise` already carries noise_strength (device-side product: no host sync)
+                y = _modconv_bias_act(x, self.weight, styles, True, noise, 1.0,
+                                      self.bias.to(x.dtype), self.activation, act_gain, act_clamp)
+                if y is not None:
+                    return y
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=(self.resample_filter if self.up > 1 else None), flip_weight=(self.up == 1),
+                             fused_modconv=(fused_modconv and not _inference_on_gpu(x, self.weight, styles)))
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
+
+
+@persistence.persistent_class
+class ToRGBLayer(torch.nn.Module):
+    """1x1 modulated conv without demodulation -> image / segmentation head (reference networks.py:670-713, w_dim > 0)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False, **unused):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        if x.size(0) > styles.size(0):
+            assert x.size(0) % styles.size(0) == 0
+            styles = styles.repeat_interleave(x.size(0) // styles.size(0), dim=0)
+        y = _modconv_bias_act(x, self.weight, styles, False, None, 0.0, self.bias.to(x.dtype), 'linear', 1.0, self.conv_clamp)
+        if y is not None:
+            return y
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+
+@persistence.persistent_class
+class SegSynthesisBlock(torch.nn.Module):
+    """Dual-path synthesis block: one conv trunk, an image head (torgb) and a semantic head (toseg) that share
+    the same w (reference networks.py:966-1139; 'skip' and 'orig' architectures, default up-sampling)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, seg_channels, is_last,
+                 architecture='skip', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False,
+                 fp16_channels_last=False, use_single_layer=False, disable_upsample=False, **layer_kwargs):
+        assert architecture in ['orig', 'skip']
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.w_dim, self.resolution = w_dim, resolution
+        self.img_channels, self.seg_channels = img_channels, seg_channels
+        self.is_last, self.architecture = is_last, architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.use_single_layer = use_single_layer
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = self.num_torgb = self.num_toseg = 0
+        layer_name = layer_kwargs.pop('layer_name', 'training.networks.SynthesisLayer')
+
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = util.construct_class_by_name(
+                class_name=layer_name, in_channels=in_channels, out_channels=out_channels, w_dim=w_dim,
+                resolution=resolution, up=(1 if disable_upsample else 2), resample_filter=resample_filter,
+                conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        if not use_single_layer:
+            self.conv1 = util.construct_class_by_name(
+                class_name=layer_name, in_channels=out_channels, out_channels=out_channels, w_dim=w_dim,
+                resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            self.num_torgb += 1
+            self.toseg = ToRGBLayer(out_channels, seg_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            self.num_toseg += 1
+
+    def _merge_skip(self, skip, x):
+        """Bring the running skip image to the resolution of x."""
+        if skip is None:
+            return None
+        if skip.size(-1) * 2 == x.size(-1):
+            return upfirdn2d.upsample2d(skip, self.resample_filter)
+        if skip.size(-1) == x.size(-1):
+            return skip
+        raise NotImplementedError
+
+    def forward(self, x, img, seg, ws, force_fp32=False, fused_modconv=None, block_noise=None, disable_rgb=False, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if fused_modconv is None:
+            with misc.suppress_tracer_warnings():
+                fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
+
+        if self.in_channels == 0:
+            x = self.const.to(dtype=dtype, memory_format=memory_format)
+            x = x.unsqueeze(0).expand(ws.shape[0], *x.size())
+            if not self.use_single_layer:
+                layer_kwargs['input_noise'] = block_noise[:, 1:2] if block_noise is not None else None
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        else:
+            x = x.to(dtype=dtype, memory_format=memory_format)
+            layer_kwargs['input_noise'] = block_noise[:, 0:1] if block_noise is not None else None
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            if not self.use_single_layer:
+                layer_kwargs['input_noise'] = block_noise[:, 1:2] if block_noise is not None else None
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        w_shared = next(w_iter) if (self.is_last or self.architecture == 'skip') else None
+        img = self._merge_skip(img, x)
+        seg = self._merge_skip(seg, x)
+        if self.is_last or self.architecture == 'skip':
+            if disable_rgb:
+                img = seg = None
+            else:
+                y = self.torgb(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                img = img.add_(y) if img is not None else y
+                y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                seg = seg.add_(y_seg) if seg is not None else y_seg
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        assert seg is None or seg.dtype == torch.float32
+        return x, img, seg

@@ -1,0 +1,357 @@
+"""`TriPlaneGenerator` — the IDE-3D "64-neural-render -> 512" generator (`training.triplane` is the module
+the reference's viewer imports it from, viz/renderer.py:196).
+
+The class itself is NOT in the reference repository: it ships inside the released pickle
+(SURVEY.md §0.1).  This module re-specifies it from the call-site evidence collected in SURVEY.md §3.5 /
+Appendix B, out of the reference's own building blocks:
+
+    ws = G.mapping(z, c)                                   gen_images.py:92
+    img, seg = G.synthesis(ws, c=c, render_params=..., noise_mode=..., return_seg=True)   gen_images.py:109
+    G.synthesis.voxel_block_resolutions / vb{res}(x, img, ws, condition_img=seg) -> (x, img, seg)
+    G.synthesis.block_resolutions / b{res},  G.synthesis.render_size,  G.synthesis.num_ws / w_dim
+    G.synthesis.renderer.sample_voxel(img_v, seg_v, pts) -> [B*M, 52]  (sigma last)        extract_shapes.py:113-147
+
+Data flow of `synthesis` (N images):
+    vb4 .. vb256 (dual-path StyleGAN2 blocks)  -> texture tri-plane img_v [N, 3*32, 256, 256]
+                                                  semantic/geometry tri-plane seg_v [N, 3*32, 256, 256]
+    renderer: 64x64 rays x 96 samples, both tri-planes gathered, decoded by two small MLPs to
+              [32 colour features | 19 semantic logits | sigma], alpha-composited  -> [N, 51, 64, 64]
+    b256, b512 (dual-path blocks) on the bilinearly 2x up-sampled 32-channel feature image with the raw RGB /
+              semantic images as skip inputs -> img [N, 3, 512, 512], seg [N, 19, 512, 512]
+
+On an MI355X the renderer stage is a single HIP launch (`training.volumetric_rendering.render_triplane_fused`).
+Every architecture number is a constructor argument (`GeneratorSpec`): the real widths are unknown and all
+parity statements are "this path vs the CPU oracle with the same spec and weights".
+"""
+
+import dataclasses
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from dnnlib import util
+from torch_utils import misc
+from torch_utils import persistence
+from torch_utils.ops import bias_act
+from training import networks
+from training import volumetric_rendering as vr
+
+
+@dataclasses.dataclass
+class GeneratorSpec:
+    """Architecture of the random-init ide3d-ffhq-64-512 generator."""
+    z_dim: int = 512
+    c_dim: int = 25
+    w_dim: int = 512
+    img_resolution: int = 512
+    img_channels: int = 3
+    seg_channels: int = 19
+    mapping_layers: int = 8
+    channel_base: int = 32768
+    channel_max: int = 512
+    plane_resolution: int = 256
+    plane_channels: int = 32          # per plane; a tri-plane tensor has 3x this
+    render_size: int = 64
+    feature_channels: int = 32        # colour feature width (first 3 = raw RGB)
+    decoder_hidden: int = 64
+    sr_channels: Optional[Dict[int, int]] = None     # SR block widths; default {256: 128, 512: 64}
+    num_steps: int = 96
+    ray_start: float = 2.25
+    ray_end: float = 3.3
+    fov: float = 18.0
+    conv_clamp: Optional[float] = None
+    clamp_mode: str = 'softplus'
+
+    def sr_resolutions(self) -> List[int]:
+        # two 2x blocks end at img_resolution: e.g. 64 -> (bilinear 128) -> 256 -> 512
+        return [self.img_resolution // 2, self.img_resolution]
+
+    def sr_widths(self) -> Dict[int, int]:
+        if self.sr_channels is not None:
+            return dict(self.sr_channels)
+        r0, r1 = self.sr_resolutions()
+        return {r0: min(self.channel_base // r0, self.channel_max), r1: min(self.channel_base // r1, self.channel_max)}
+
+    def voxel_resolutions(self) -> List[int]:
+        return [2 ** i for i in range(2, int(np.log2(self.plane_resolution)) + 1)]
+
+    def voxel_width(self, res: int) -> int:
+        return min(self.channel_base // res, self.channel_max)
+
+
+def tiny_spec(**overrides) -> GeneratorSpec:
+    """A seconds-on-CPU configuration with the same topology (used by tests and golden fixtures)."""
+    base = dict(z_dim=32, c_dim=25, w_dim=32, img_resolution=64, mapping_layers=2, channel_base=256, channel_max=16,
+                plane_resolution=32, plane_channels=16, render_size=8, feature_channels=8, seg_channels=5,
+                decoder_hidden=32, num_steps=12)
+    base.update(overrides)
+    return GeneratorSpec(**base)
+
+
+@persistence.persistent_class
+class VoxelBlock(networks.SegSynthesisBlock):
+    """`vb{res}`: dual-path block with the call signature the reference drivers use
+    (`block(x, img, ws, condition_img=seg) -> (x, img, seg)`, extract_shapes.py:126-129)."""
+
+    def forward(self, x, img, ws, condition_img=None, **kwargs):
+        return super().forward(x, img, condition_img, ws, **kwargs)
+
+
+@persistence.persistent_class
+class TriplaneDecoder(torch.nn.Module):
+    """Two 2-layer MLPs: geometry/semantic branch (sigma + seg logits) on the semantic tri-plane feature,
+    texture branch (colour features) on the texture tri-plane feature.  Hidden activation softplus."""
+
+    def __init__(self, in_channels, hidden, feature_channels, seg_channels):
+        super().__init__()
+        self.in_channels, self.hidden = in_channels, hidden
+        self.feature_channels, self.seg_channels = feature_channels, seg_channels
+        self.geo0 = networks.FullyConnectedLayer(in_channels, hidden, activation='softplus')
+        self.geo1 = networks.FullyConnectedLayer(hidden, 1 + seg_channels)
+        self.tex0 = networks.FullyConnectedLayer(in_channels, hidden, activation='softplus')
+        self.tex1 = networks.FullyConnectedLayer(hidden, feature_channels)
+
+    def forward(self, tex_feat, geo_feat):
+        """[M, C] features -> [M, feature + seg + 1] with sigma last."""
+        g = self.geo1(self.geo0(geo_feat))
+        t = self.tex1(self.tex0(tex_feat))
+        return torch.cat([t, g[:, 1:], g[:, :1]], dim=1)
+
+    def kernel_weights(self):
+        """Effective (gain-folded) weights in the layout `ide3d_render_rays` expects."""
+        out = {}
+        for name, layer in (('geo_w0', self.geo0), ('geo_w1', self.geo1), ('tex_w0', self.tex0), ('tex_w1', self.tex1)):
+            w, b = layer.effective(torch.float32)
+            out[name] = w.contiguous()
+            out[name.replace('_w', '_b')] = b.contiguous()
+        return out
+
+
+@persistence.persistent_class
+class TriplaneRenderer(torch.nn.Module):
+    """`G.synthesis.renderer`: tri-plane sampling + decoding + volume integration."""
+
+    def __init__(self, spec: GeneratorSpec):
+        super().__init__()
+        self.spec = spec
+        self.decoder = TriplaneDecoder(spec.plane_channels, spec.decoder_hidden, spec.feature_channels, spec.seg_channels)
+
+    # -- point queries ---------------------------------------------------------------------------------
+    def sample_voxel(self, img_v, seg_v, pts, sigma_only=False):
+        """Features at world points.  img_v / seg_v [B, 3C, H, W], pts [B, M, 3] -> [B*M, feat + seg + 1]
+        (sigma last; extract_shapes.py:146).  `sigma_only=True` returns [B*M] densities."""
+        if self._hip_ok(img_v, seg_v, pts):
+            vr._init()
+            tex, geo = _as_channels_last(img_v), _as_channels_last(seg_v)
+            out = vr._plugin.sample_voxel(tex, geo, self.decoder.kernel_weights(), pts.float(), sigma_only=sigma_only)
+            if out is not None:
+                return out
+        geo_feat = util.sample_from_triplane(pts, seg_v)
+        tex_feat = util.sample_from_triplane(pts, img_v)
+        out = self.decoder(tex_feat, geo_feat)
+        return out[:, -1] if sigma_only else out
+
+    @staticmethod
+    def _hip_ok(*tensors):
+        if any(t.device.type != 'cuda' or t.dtype != torch.float32 for t in tensors):
+            return False
+        return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
+    # -- full rendering -----------------------------------------------------------------------------------
+    def forward(self, img_v, seg_v, cam2world, fov=None, num_steps=None, ray_start=None, ray_end=None, img_size=None,
+                nerf_noise=0.0, jitter=None, sigma_noise=None, white_back=False, clamp_mode=None, **unused):
+        """Render N views.  Returns (features [N, feat+seg, R, R], depth [N, 1, R, R], weight sum [N, 1, R, R]).
+
+        jitter: None -> draw U[0,1) per sample on the device (the reference always jitters,
+                volumetric_rendering.py:113); False -> no jitter; tensor [N, R*R, S] -> use these draws.
+        """
+        sp = self.spec
+        fov = sp.fov if fov is None else fov
+        steps = sp.num_steps if num_steps is None else num_steps
+        t0 = sp.ray_start if ray_start is None else ray_start
+        t1 = sp.ray_end if ray_end is None else ray_end
+        size = sp.render_size if img_size is None else img_size
+        clamp_mode = sp.clamp_mode if clamp_mode is None else clamp_mode
+        n, device = img_v.shape[0], img_v.device
+        rays = size * size
+        if jitter is None:
+            jitter = torch.rand([n, rays, steps], device=device)
+        elif jitter is False:
+            jitter = None
+        if sigma_noise is None and nerf_noise:
+            sigma_noise = torch.randn([n, rays, steps], device=device) * nerf_noise
+
+        if self._hip_ok(img_v, seg_v, cam2world):
+            res = vr.render_triplane_fused(_as_channels_last(img_v), _as_channels_last(seg_v), self.decoder.kernel_weights(),
+                                           cam2world.float(), fov, (size, size), steps, t0, t1, jitter=jitter,
+                                           sigma_noise=sigma_noise, clamp_mode=clamp_mode, white_back=white_back)
+            if res is not None:
+                return res
+
+        # step-wise definition (CPU / autograd / configurations outside the fused kernel)
+        points, z_vals, rays_d_cam = vr.get_initial_rays_trig(n, steps, device, fov, (size, size), t0, t1)
+        pts, z_vals, _rd, _ro, _p, _y = vr.transform_sampled_points(
+            points, z_vals, rays_d_cam, device, h_stddev=0, v_stddev=0, camera=cam2world, mode=None,
+            jitter=(jitter.unsqueeze(-1) if jitter is not None else torch.full_like(z_vals, 0.5)))
+        out = self.sample_voxel(img_v, seg_v, pts.reshape(n, -1, 3)).reshape(n, rays, steps, -1)
+        noise = sigma_noise.unsqueeze(-1) if sigma_noise is not None else None
+        feat, depth, weights = vr.fancy_integration(out, rays_d_cam, z_vals, device, noise_std=(1.0 if noise is not None else 0.0),
+                                                    white_back=white_back, clamp_mode=clamp_mode, noise=noise)
+        feat = feat.permute(0, 2, 1).reshape(n, -1, size, size)
+        depth = depth.permute(0, 2, 1).reshape(n, 1, size, size)
+        wsum = weights.sum(2).permute(0, 2, 1).reshape(n, 1, size, size)
+        return feat, depth, wsum
+
+
+def _as_channels_last(t):
+    return t if t.stride(1) == 1 else t.contiguous(memory_format=torch.channels_last)
+
+
+@persistence.persistent_class
+class TriplaneSynthesisNetwork(torch.nn.Module):
+    """`G.synthesis`."""
+
+    def __init__(self, spec: GeneratorSpec):
+        super().__init__()
+        self.spec = spec
+        self.w_dim = spec.w_dim
+        self.img_resolution = spec.img_resolution
+        self.img_channels = spec.img_channels
+        self.seg_channels = spec.seg_channels
+        self.render_size = spec.render_size
+        self.voxel_block_resolutions = spec.voxel_resolutions()
+        self.block_resolutions = spec.sr_resolutions()
+        plane_ch = 3 * spec.plane_channels
+        layer_kwargs = dict(layer_name='training.networks.SynthesisLayer')
+
+        self.num_ws = 0
+        for res in self.voxel_block_resolutions:
+            cin = spec.voxel_width(res // 2) if res > 4 else 0
+            block = VoxelBlock(cin, spec.voxel_width(res), w_dim=spec.w_dim, resolution=res, img_channels=plane_ch,
+                               seg_channels=plane_ch, is_last=False, architecture='skip', conv_clamp=spec.conv_clamp,
+                               **layer_kwargs)
+            self.num_ws += block.num_conv
+            setattr(self, f'vb{res}', block)
+
+        self.renderer = TriplaneRenderer(spec)
+
+        widths = spec.sr_widths()
+        cin = spec.feature_channels
+        for res in self.block_resolutions:
+            is_last = (res == self.img_resolution)
+            block = networks.SegSynthesisBlock(cin, widths[res], w_dim=spec.w_dim, resolution=res,
+                                               img_channels=spec.img_channels, seg_channels=spec.seg_channels,
+                                               is_last=is_last, architecture='skip', conv_clamp=spec.conv_clamp, **layer_kwargs)
+            self.num_ws += block.num_conv
+            if is_last:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+            cin = widths[res]
+
+    # -- pieces (public so that drivers / caches can call them separately) ----------------------------------
+    def split_ws(self, ws):
+        """Per-block w slices, StyleGAN2 convention (extract_shapes.py:113-124)."""
+        with torch.autograd.profiler.record_function('split_ws'):
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            ws = ws.to(torch.float32)
+            voxel_ws, block_ws, w_idx = [], [], 0
+            for res in self.voxel_block_resolutions:
+                block = getattr(self, f'vb{res}')
+                voxel_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+                w_idx += block.num_conv
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+                w_idx += block.num_conv
+        return voxel_ws, block_ws
+
+    def backbone(self, voxel_ws, **block_kwargs):
+        """ws -> (texture tri-plane, semantic tri-plane); pose independent."""
+        x_v = img_v = seg_v = None
+        for res, cur_ws in zip(self.voxel_block_resolutions, voxel_ws):
+            x_v, img_v, seg_v = getattr(self, f'vb{res}')(x_v, img_v, cur_ws, condition_img=seg_v, **block_kwargs)
+        return img_v, seg_v
+
+    def superres(self, feat, block_ws, **block_kwargs):
+        """[N, feat+seg, R, R] composited features -> (img, seg) at full resolution."""
+        fc = self.spec.feature_channels
+        size = self.block_resolutions[0] // 2
+        up = lambda t: torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', align_corners=False)
+        x = up(feat[:, :fc])
+        img = up(feat[:, :self.img_channels])
+        seg = up(feat[:, fc:])
+        for res, cur_ws in zip(self.block_resolutions, block_ws):
+            x, img, seg = getattr(self, f'b{res}')(x, img, seg, cur_ws, **block_kwargs)
+        return img, seg
+
+    def forward(self, ws, c=None, render_params=None, noise_mode='const', return_seg=False, return_raw=False,
+                return_dict=False, force_fp32=False, cond_img=None, ray_jitter=None, cached_planes=None, **unused):
+        """ws [N, num_ws, w_dim], c [N, 25] = flattened cam2world (16) + intrinsics (9)."""
+        assert c is not None, 'synthesis needs the 25-D camera label c'
+        render_params = dict(render_params or {})
+        voxel_ws, block_ws = self.split_ws(ws)
+        block_kwargs = dict(noise_mode=noise_mode, force_fp32=True)
+        if cached_planes is not None:
+            img_v, seg_v = cached_planes
+        else:
+            img_v, seg_v = self.backbone(voxel_ws, **block_kwargs)
+        cam2world = c[:, :16].reshape(-1, 4, 4).to(torch.float32)
+        feat, depth, wsum = self.renderer(
+            img_v, seg_v, cam2world, fov=render_params.get('fov'), num_steps=render_params.get('num_steps'),
+            ray_start=render_params.get('ray_start'), ray_end=render_params.get('ray_end'),
+            nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter)
+        img, seg = self.superres(feat, block_ws, **block_kwargs)
+        img_raw = feat[:, :self.img_channels]
+        if return_dict:
+            return dict(image=img, image_seg=seg, image_raw=img_raw, image_depth=depth, planes=(img_v, seg_v))
+        if return_seg and return_raw:
+            return img, seg, img_raw
+        if return_seg:
+            return img, seg
+        if return_raw:
+            return img, img_raw
+        return img
+
+
+@persistence.persistent_class
+class TriPlaneGenerator(torch.nn.Module):
+    """`G`: mapping + synthesis, with the attributes the reference drivers read."""
+
+    def __init__(self, spec: Optional[GeneratorSpec] = None, **spec_overrides):
+        super().__init__()
+        if spec is None:
+            spec = GeneratorSpec(**spec_overrides)
+        elif spec_overrides:
+            spec = dataclasses.replace(spec, **spec_overrides)
+        self.spec = spec
+        self.z_dim, self.c_dim, self.w_dim = spec.z_dim, spec.c_dim, spec.w_dim
+        self.img_resolution, self.img_channels = spec.img_resolution, spec.img_channels
+        self.synthesis = TriplaneSynthesisNetwork(spec)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = networks.MappingNetwork(z_dim=spec.z_dim, c_dim=spec.c_dim, w_dim=spec.w_dim, num_ws=self.num_ws,
+                                               num_layers=spec.mapping_layers)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, c=c, **synthesis_kwargs)
+
+
+# ---- camera labels used by the reference drivers ----------------------------------------------------------
+
+INTRINSICS = (4.2647, 0.0, 0.5, 0.0, 4.2647, 0.5, 0.0, 0.0, 1.0)     # gen_images.py:87,107
+
+
+def conditioning_label(device='cpu'):
+    """Frontal 25-D label the mapping network is conditioned on (gen_images.py:87)."""
+    pose = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 2.7, 0, 0, 0, 1]
+    return torch.tensor(pose + list(INTRINSICS), dtype=torch.float32, device=device).reshape(1, -1)
+
+
+def camera_label(yaw, pitch=math.pi * 0.5, radius=2.7, device='cpu'):
+    """25-D label of the gen_images.py pose loop (:104-107): camera on a sphere looking at the origin."""
+    cam, _phi, _theta = vr.sample_camera_positions(device, n=1, r=radius, horizontal_mean=yaw + math.pi * 0.5,
+                                                   vertical_mean=pitch, mode=None)
+    c2w = vr.create_cam2world_matrix(-cam, cam, device=device).reshape(1, -1)
+    return torch.cat((c2w, torch.tensor(INTRINSICS, dtype=torch.float32, device=device).reshape(1, -1)), -1)

@@ -1,0 +1,280 @@
+/*
+ * ide3d_hip.h — C ABI of libide3d_hip.so, the MI355X (gfx950) implementation of the
+ * IDE-3D rendering hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers / sizes / strides and a
+ * `void* stream` (a hipStream_t; NULL = the default stream), launches asynchronously on that
+ * stream and returns 0 on success or a negative IDE3D_E* code.  After a failure
+ * `ide3d_last_error()` returns a human readable, thread-local message.  No entry point
+ * allocates, frees or synchronises; the caller owns every buffer.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * IDE-3D repository, MrTornado24/IDE-3D).
+ */
+#ifndef IDE3D_HIP_H_
+#define IDE3D_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- common --------------------------------------------------------------------------- */
+
+#define IDE3D_OK            0
+#define IDE3D_EINVAL       (-1)   /* bad argument (the reference raises via TORCH_CHECK)      */
+#define IDE3D_ENOKERNEL    (-2)   /* no specialised kernel: caller must use its generic path  */
+#define IDE3D_ELAUNCH      (-3)   /* hipLaunchKernel / runtime error                          */
+
+/* element types of activation tensors */
+#define IDE3D_F32  0
+#define IDE3D_F16  1
+#define IDE3D_BF16 2
+#define IDE3D_F64  3
+
+const char* ide3d_last_error(void);
+/* ABI version (bumped on any signature change) and the gfx arch string the library was built for. */
+int         ide3d_abi_version(void);
+const char* ide3d_build_arch(void);
+
+/* ---- bias_act ------------------------------------------------------------------------- */
+/*
+ * Replaces `_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)`
+ * (torch_utils/ops/bias_act.cpp:32, registered :94-97; kernel bias_act.cu:23).
+ *   grad = 0: y = clamp(act(x + b) * gain)
+ *   grad = 1: y = d/dx of the above, applied to incoming gradient x (=dy), using xref/yref
+ *   grad = 2: second-order term (needs dy = the first-order incoming gradient)
+ * x/xref/yref/dy/y are dense with identical memory layout, `size_x` elements of `dtype`.
+ * b (may be NULL) has `size_b` elements of `dtype`; element i uses b[(i / step_b) % size_b]
+ * (step_b = x.stride(dim), bias_act.cpp:80-82).  act is the reference's cuda_idx 1..9
+ * (bias_act.py:22-30).  clamp < 0 disables clamping.
+ */
+int ide3d_bias_act(const void* x, const void* b, const void* xref, const void* yref,
+                   const void* dy, void* y, int dtype, int grad, int act,
+                   float alpha, float gain, float clamp,
+                   int64_t size_x, int64_t size_b, int64_t step_b, void* stream);
+
+/* ---- upfirdn2d ------------------------------------------------------------------------ */
+/*
+ * Replaces `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+ * flip, gain)` (torch_utils/ops/upfirdn2d.cpp:16, registered :102-105; kernels
+ * upfirdn2d.cu:29,97).  x is [n, c, in_h, in_w] with arbitrary element strides (NCHW or
+ * channels_last), f is a float32 [f_h, f_w] tap array with element strides, y is
+ * [n, c, out_h, out_w] with its own strides; out = (in*up + pad0 + pad1 - f + down) / down
+ * (upfirdn2d.cpp:35-36) must match what the caller allocated.
+ */
+typedef struct ide3d_upfirdn2d_params {
+    const void*  x;            /* input activations                                   */
+    const float* f;            /* filter taps (float32, device)                       */
+    void*        y;            /* output activations                                  */
+    int32_t dtype;             /* IDE3D_F32 / F16 / BF16 / F64                         */
+    int32_t n, c, in_h, in_w;  /* input shape                                         */
+    int32_t out_h, out_w;      /* output spatial shape                                */
+    int64_t x_stride[4];       /* element strides of x: n, c, h, w                    */
+    int64_t y_stride[4];       /* element strides of y: n, c, h, w                    */
+    int32_t f_h, f_w;          /* filter shape                                        */
+    int64_t f_stride[2];       /* element strides of f: h, w                          */
+    int32_t up_x, up_y, down_x, down_y;
+    int32_t pad_x0, pad_y0;    /* leading pads (trailing pads are implied by out size) */
+    int32_t flip;              /* 1 = correlation (flip_filter=True)                  */
+    float   gain;
+} ide3d_upfirdn2d_params;
+
+int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* p, void* stream);
+
+/* ---- filtered_lrelu ------------------------------------------------------------------- */
+/*
+ * Replaces `_plugin.filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy,
+ * gain, slope, clamp, flip_filters, writeSigns)` (torch_utils/ops/filtered_lrelu.cpp:16,
+ * parameter block filtered_lrelu.h:14-53; kernel filtered_lrelu.cu:139).  One launch does
+ * bias -> up-FIR(gain up^2) -> gain*lrelu(slope) -> clamp -> down-FIR.  Filters travel in the
+ * kernel argument block / LDS (no process-global constant buffer: stream-safe, unlike
+ * filtered_lrelu.cu:77-78).  fu/fd are float32; shape [h, w] with f*_h = 0 meaning a separable
+ * 1-D filter of f*_w taps (filtered_lrelu.cpp:49-50).
+ * Sign tensor s (uint8, 4 x 2-bit codes per byte; bit0 = negative, bit1 = clamped;
+ * filtered_lrelu.cu:494-519) is [n, c, s_h, s_w_bytes] contiguous.  sign_mode: 0 none,
+ * 1 write, 2 read.  Returns IDE3D_ENOKERNEL when the tile does not fit the LDS budget or the
+ * filter exceeds the supported tap count (the reference's `return_code = -1`,
+ * filtered_lrelu.cpp:52-56): the caller then runs the generic path with
+ * ide3d_filtered_lrelu_act.
+ */
+typedef struct ide3d_filtered_lrelu_params {
+    const void*  x;
+    void*        y;
+    const void*  b;            /* per-channel bias, dtype of x, never NULL            */
+    uint8_t*     s;            /* sign tensor or NULL                                 */
+    const float* fu;
+    const float* fd;
+    int32_t dtype;             /* IDE3D_F32 / F16 / BF16                               */
+    int32_t n, c, in_h, in_w;
+    int32_t out_h, out_w;
+    int64_t x_stride[4];       /* element strides n, c, h, w                          */
+    int64_t y_stride[4];
+    int32_t fu_w, fu_h;        /* fu_h == 0 -> separable                              */
+    int32_t fd_w, fd_h;
+    int64_t fu_stride[2];      /* element strides: h, w (h unused when separable)     */
+    int64_t fd_stride[2];
+    int32_t up, down;
+    int32_t pad_x0, pad_y0;
+    int32_t s_w_bytes, s_h;    /* sign tensor shape (width in bytes)                  */
+    int32_t s_ofs_x, s_ofs_y;  /* sign offset (elements), sx/sy of the reference      */
+    int32_t sw_limit;          /* active sign width in bytes, filtered_lrelu.cpp:125  */
+    int32_t sign_mode;         /* 0 none, 1 write, 2 read                             */
+    int32_t flip;
+    float   gain, slope, clamp;
+} ide3d_filtered_lrelu_params;
+
+int ide3d_filtered_lrelu(const ide3d_filtered_lrelu_params* p, void* stream);
+
+/*
+ * Replaces `_plugin.filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns)`
+ * (torch_utils/ops/filtered_lrelu.cpp:213; kernel filtered_lrelu.cu:1105).  In-place
+ * gain*lrelu*clamp on x [n, c, h, w] (element strides) with sign write / read.  s_w is the
+ * sign width in *elements* (a multiple of 16 when writing), s is contiguous.
+ */
+int ide3d_filtered_lrelu_act(void* x, uint8_t* s, int dtype,
+                             int32_t n, int32_t c, int32_t h, int32_t w,
+                             const int64_t x_stride[4],
+                             int32_t s_w, int32_t s_h, int32_t s_ofs_x, int32_t s_ofs_y,
+                             float gain, float slope, float clamp, int sign_mode, void* stream);
+
+/* ---- tri-plane feature gather ----------------------------------------------------------- */
+/*
+ * Replaces `dnnlib.util.sample_from_triplane(coordinates, grid)` (dnnlib/util.py:580-617:
+ * three `grid_sample(bilinear, zeros, align_corners=False)` calls — torch_utils/ops/
+ * grid_sample_gradfix.py:26-29 — on the xy, yz and xz planes, summed).
+ * planes: float32 [n, 3*C, H, W] addressed through element strides (NCHW or channels_last;
+ *         channels_last is the fast path: each bilinear tap is one contiguous C*4-byte read).
+ * coords: float32 [n, m, 3] contiguous, world coordinates in grid_sample's [-1, 1] convention.
+ * out:    float32 [n*m, C] contiguous, row = n*m_total + m.
+ * Tap index math is bit-exact w.r.t. ATen grid_sampler_2d: u = ((c + 1) * size - 1) / 2
+ * evaluated add -> mul -> sub -> mul(0.5) in fp32 with no FMA contraction.
+ */
+int ide3d_triplane_sample(const float* planes, const int64_t plane_stride[4],
+                          int32_t n, int32_t C, int32_t H, int32_t W,
+                          const float* coords, int64_t m, float* out, void* stream);
+
+/*
+ * Debug / parity hook: writes, per sample and plane, the integer tap origin (floor(u),
+ * floor(v)) and the in-bounds mask of the four taps, so tests can assert bit-exact index
+ * math against the oracle.  taps: int32 [n*m, 3, 3] = (ix0, iy0, mask4).
+ */
+int ide3d_triplane_taps(int32_t H, int32_t W, const float* coords, int64_t n_times_m,
+                        int32_t* taps, void* stream);
+
+/*
+ * Backward of the gather w.r.t. the planes (atomic scatter-add into grad_planes, which the
+ * caller zero-fills) and optionally w.r.t. the coordinates (grad_coords may be NULL).
+ * Replaces aten::grid_sampler_2d_backward as used by grid_sample_gradfix.py:55-60.
+ */
+int ide3d_triplane_sample_backward(const float* grad_out, const float* planes,
+                                   const int64_t plane_stride[4],
+                                   int32_t n, int32_t C, int32_t H, int32_t W,
+                                   const float* coords, int64_t m,
+                                   float* grad_planes, const int64_t grad_plane_stride[4],
+                                   float* grad_coords, void* stream);
+
+/* ---- volume compositing ----------------------------------------------------------------- */
+/*
+ * Replaces `training.volumetric_rendering.fancy_integration` (volumetric_rendering.py:34-74).
+ * rgb_sigma: float32 [rays, steps, ch+1] contiguous (sigma last), z_vals: [rays, steps],
+ * dir_norm: [rays] (= ||rays_d_cam||), noise: [rays, steps] or NULL (already scaled by
+ * noise_std).  Outputs: rgb [rays, ch], depth [rays], weights [rays, steps] (NULL = skip).
+ * clamp_mode: 0 softplus, 1 relu.  fill_mode: 0 none, 1 'debug', 2 'weight'.
+ * One wavefront integrates one ray: lane-local alpha, wave-wide exclusive prefix product of
+ * (1 - alpha + 1e-10) by shuffles, then a shuffle reduction per channel.
+ */
+int ide3d_composite(const float* rgb_sigma, const float* z_vals, const float* dir_norm,
+                    const float* noise, int64_t rays, int32_t steps, int32_t ch,
+                    int clamp_mode, int last_back, int white_back, float max_depth,
+                    int fill_mode, float* rgb, float* depth, float* weights, void* stream);
+
+/* ---- fused ray-marcher ------------------------------------------------------------------ */
+/*
+ * One launch for steps 3-7 of G.synthesis: camera-space sample points
+ * (get_initial_rays_trig, volumetric_rendering.py:77-97) -> optional stratified jitter
+ * (perturb_points :99-105) -> cam2world transform (transform_sampled_points :108-136) ->
+ * two tri-plane gathers (dnnlib/util.py:580) -> decoder MLPs (renderer.sample_voxel, source
+ * absent: spec in DESIGN.md) -> fancy_integration (:34-74).
+ *
+ * rays_d_cam [rays_per_img, 3] and z_lin [steps] are produced on the host with torch.linspace
+ * exactly as the reference does, so the kernel never re-derives them.
+ * cam2world: [n, 16] row-major 4x4.  jitter: [n, rays_per_img, steps] uniform [0,1) or NULL.
+ * tex_planes / geo_planes: [n, 3*C, H, W] through element strides.
+ * MLP weights (float32, row-major [out, in], already multiplied by their runtime gains):
+ *   geo: w0 [hidden, C], b0 [hidden], w1 [1 + seg_ch, hidden], b1 [1 + seg_ch]
+ *   tex: w0 [hidden, C], b0 [hidden], w1 [feat_ch, hidden],    b1 [feat_ch]
+ * out_feat: [n, feat_ch + seg_ch, rays_per_img] (channel-major image planes),
+ * out_depth: [n, rays_per_img], out_wsum: [n, rays_per_img] (either may be NULL).
+ */
+typedef struct ide3d_render_params {
+    const float* rays_d_cam;
+    const float* z_lin;
+    const float* cam2world;
+    const float* jitter;
+    const float* sigma_noise;   /* [n, rays, steps] pre-scaled density noise or NULL */
+    const float* tex_planes;
+    const float* geo_planes;
+    int64_t tex_stride[4];
+    int64_t geo_stride[4];
+    const float* geo_w0; const float* geo_b0; const float* geo_w1; const float* geo_b1;
+    const float* tex_w0; const float* tex_b0; const float* tex_w1; const float* tex_b1;
+    int32_t n, rays_per_img, steps;
+    int32_t C, H, W;
+    int32_t hidden, feat_ch, seg_ch;
+    int32_t clamp_mode, last_back, white_back;
+    float   max_depth;
+    float*  out_feat;
+    float*  out_depth;
+    float*  out_wsum;
+} ide3d_render_params;
+
+int ide3d_render_rays(const ide3d_render_params* p, void* stream);
+
+/*
+ * `renderer.sample_voxel(img_v, seg_v, pts)` (call site extract_shapes.py:146): the same two
+ * gathers + MLPs for arbitrary points, no compositing.  out: [n*m, feat_ch + seg_ch + 1]
+ * (sigma last).  If sigma_only != 0 only out_sigma [n*m] is written (the 256^3 density-cube
+ * query) and the texture branch is skipped.
+ */
+int ide3d_sample_voxel(const ide3d_render_params* p, const float* pts, int64_t m,
+                       float* out, float* out_sigma, int sigma_only, void* stream);
+
+/* ---- modulated 3x3 / 1x1 convolution (MFMA implicit GEMM) --------------------------------- */
+/*
+ * Replaces the ATen conv behind `conv2d_gradfix.conv2d` for the StyleGAN2 modulated
+ * convolution (inversion/networks.py:55-130 `modulated_conv2d`, stride 1, `flip_weight=True`)
+ * with its epilogue (`+ noise`, `bias_act(lrelu)`, networks.py:457-512) fused:
+ *   y[n,o,:,:] = act( d[n,o] * sum_{i,ky,kx} w[o,i,ky,kx] * s[n,i] * x[n,i,y+ky-p,x+kx-p]
+ *                     + noise_strength * noise[:, :] + b[o] ) * act_gain, clamped.
+ * x [n, cin, h, w], y [n, cout, h, w] NCHW contiguous float32; w [cout, cin, k, k];
+ * styles s [n, cin]; dcoefs d [n, cout] or NULL (no demodulation); noise [h, w] or NULL;
+ * bias [cout] or NULL.  act: 1 linear, 3 lrelu (bias_act cuda_idx).  k in {1, 3}.
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 adds).
+ */
+typedef struct ide3d_modconv_params {
+    const float* x; const float* w; const float* styles; const float* dcoefs;
+    const float* noise; const float* bias; float* y;
+    int32_t n, cin, cout, h, w_, k;
+    float noise_strength;
+    int32_t act; float alpha, gain, clamp;
+} ide3d_modconv_params;
+
+int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
+
+/* ---- output post-processing -------------------------------------------- */
+/*
+ * `mask2color(seg)` (dnnlib/seg_tools.py:75-81: argmax over the class channel + palette) and
+ * the uint8 conversion of `layout_grid` (dnnlib/util.py:632-646), fused: writes one
+ * [n, H, 2W, 3] uint8 frame per image = RGB | coloured segmentation side by side, the
+ * `image_seg` layout of gen_videos.py:133-135.
+ * img [n, 3, H, W], seg [n, classes, H, W] float32 NCHW; palette uint8 [classes, 3].
+ */
+int ide3d_frame_u8(const float* img, const float* seg, const uint8_t* palette,
+                   int32_t n, int32_t classes, int32_t H, int32_t W, uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDE3D_HIP_H_ */

@@ -1,0 +1,412 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product (`ide-3d_amd/`), `bench.py`'s timed GPU
+path or anything that ships; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may use it.
+
+Independent CPU restatement (numpy / plain torch fp32-fp64 on CPU) of the custom ops on the IDE-3D render path.
+Each function cites the reference definition it restates (paths relative to MrTornado24/IDE-3D).  The restatement
+is deliberately written differently from both the reference `_ref` code and the product code (direct index
+formulas / explicit loops over taps instead of pad + grouped conv) so that agreement is evidence.
+
+Pinning: `tests/golden/*.npz` holds outputs of the REFERENCE's own Python code (`impl='ref'` paths and the
+`training.volumetric_rendering` / `dnnlib.util` / `inversion.networks` functions) generated in the build container by
+`oracle/make_golden.py`; `tests/test_oracle_golden.py` checks every function here against them.  The reference has
+no tests or golden vectors of its own, and the arithmetic underneath is ATen's (not in the reference
+tree): parity is pinned to reference-run outputs under torch 2.10 CPU kernels.
+"""
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------------------------------
+# bias_act  (torch_utils/ops/bias_act.py:52-120, formulas bias_act.cu:51-142)
+# ---------------------------------------------------------------------------------------------------
+
+_ACT_DEFAULTS = {  # name: (def_alpha, def_gain)  bias_act.py:21-31
+    'linear': (0.0, 1.0), 'relu': (0.0, math.sqrt(2)), 'lrelu': (0.2, math.sqrt(2)), 'tanh': (0.0, 1.0),
+    'sigmoid': (0.0, 1.0), 'elu': (0.0, 1.0), 'selu': (0.0, 1.0), 'softplus': (0.0, 1.0), 'swish': (0.0, math.sqrt(2)),
+}
+
+
+def _act(name, x, alpha):
+    if name == 'linear':
+        return x
+    if name == 'relu':
+        return np.where(x > 0, x, 0.0)
+    if name == 'lrelu':
+        return np.where(x > 0, x, x * alpha)
+    if name == 'tanh':
+        return np.tanh(x)
+    if name == 'sigmoid':
+        return 1.0 / (1.0 + np.exp(-x))
+    if name == 'elu':
+        return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    if name == 'selu':
+        sc, al = 1.0507009873554804934193349852946, 1.6732632423543772848170429916717
+        return sc * np.where(x > 0, x, al * np.expm1(np.minimum(x, 0)))
+    if name == 'softplus':
+        return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+    if name == 'swish':
+        return x / (1.0 + np.exp(-x))
+    raise KeyError(name)
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    """y = clamp(act(x + b) * gain), computed in float64 and rounded once to x's dtype."""
+    t = torch.as_tensor(x)
+    a = t.detach().cpu().double().numpy()
+    def_alpha, def_gain = _ACT_DEFAULTS[act]
+    alpha = def_alpha if alpha is None else float(alpha)
+    gain = def_gain if gain is None else float(gain)
+    if b is not None:
+        shape = [1] * a.ndim
+        shape[dim] = -1
+        a = a + torch.as_tensor(b).detach().cpu().double().numpy().reshape(shape)
+    y = _act(act, a, alpha) * gain
+    if clamp is not None and clamp >= 0:
+        y = np.clip(y, -clamp, clamp)
+    return torch.from_numpy(np.ascontiguousarray(y)).to(t.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+# upfirdn2d  (torch_utils/ops/upfirdn2d.py:118-211; output size upfirdn2d.cpp:35-36)
+# ---------------------------------------------------------------------------------------------------
+
+def _pad4(padding):
+    if isinstance(padding, int):
+        padding = [padding] * 4
+    if len(padding) == 2:
+        padding = [padding[0], padding[0], padding[1], padding[1]]
+    return [int(p) for p in padding]
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """Direct evaluation of  out[oy,ox] = gain * sum_k U[oy*dy + ky - py0, ox*dx + kx - px0] * g[ky,kx]
+    (g = f flipped unless flip_filter; separable f = outer product) in float64, one tap at a time."""
+    t = torch.as_tensor(x)
+    a = t.detach().cpu().double().numpy()
+    n, c, ih, iw = a.shape
+    ux, uy = _pair(up)
+    dx, dy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    if f is None:
+        fk = np.ones([1, 1])
+    else:
+        fk = torch.as_tensor(f).detach().cpu().double().numpy()
+        if fk.ndim == 1:
+            fk = np.outer(fk, fk)
+    fh, fw = fk.shape
+    g = fk if flip_filter else fk[::-1, ::-1]
+    ow = (iw * ux + px0 + px1 - fw + dx) // dx
+    oh = (ih * uy + py0 + py1 - fh + dy) // dy
+    # zero-upsampled + padded canvas large enough for every tap
+    U = np.zeros([n, c, ih * uy + max(py0, 0) + max(py1, 0) + fh, iw * ux + max(px0, 0) + max(px1, 0) + fw])
+    oy0, ox0 = max(py0, 0), max(px0, 0)          # canvas offset of upsampled pixel (0,0) when pad >= 0
+    U[:, :, oy0:oy0 + ih * uy:uy, ox0:ox0 + iw * ux:ux] = a
+    cy, cx = oy0 - py0, ox0 - px0                # canvas coordinate of padded-image pixel (0,0)
+    out = np.zeros([n, c, oh, ow])
+    for ky in range(fh):
+        for kx in range(fw):
+            ys = cy + ky + np.arange(oh) * dy
+            xs = cx + kx + np.arange(ow) * dx
+            out += g[ky, kx] * U[:, :, ys[:, None], xs[None, :]]
+    return torch.from_numpy(out * gain).to(t.dtype)
+
+
+def setup_filter(f, normalize=True, flip_filter=False, gain=1, separable=None):
+    """upfirdn2d.py:70-114."""
+    k = np.asarray(1 if f is None else f, dtype=np.float32)
+    if k.ndim == 0:
+        k = k[None]
+    if separable is None:
+        separable = (k.ndim == 1 and k.size >= 8)
+    if k.ndim == 1 and not separable:
+        k = np.outer(k, k).astype(np.float32)
+    if normalize:
+        k = k / k.sum(dtype=np.float32)
+    if flip_filter:
+        k = k[::-1].copy() if k.ndim == 1 else k[::-1, ::-1].copy()
+    k = (k * np.float32(gain ** (k.ndim / 2))).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(k))
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:313-348."""
+    ux, uy = _pair(up)
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = (f.shape[-1], f.shape[0])
+    p = [px0 + (fw + ux - 1) // 2, px1 + (fw - ux) // 2, py0 + (fh + uy - 1) // 2, py1 + (fh - uy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * ux * uy)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:352-387."""
+    dx, dy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = (f.shape[-1], f.shape[0])
+    p = [px0 + (fw - dx + 1) // 2, px1 + (fw - dx) // 2, py0 + (fh - dy + 1) // 2, py1 + (fh - dy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:277-309."""
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = (f.shape[-1], f.shape[0])
+    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain)
+
+
+# ---------------------------------------------------------------------------------------------------
+# filtered_lrelu  (torch_utils/ops/filtered_lrelu.py:121-153; sign codes filtered_lrelu.cu:494-519)
+# ---------------------------------------------------------------------------------------------------
+
+def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=math.sqrt(2), slope=0.2, clamp=None,
+                   flip_filter=False, return_signs=False):
+    """bias -> up-FIR (gain up^2) -> gain * lrelu -> clamp -> down-FIR, float64 internally.
+    With return_signs also returns the per-element 2-bit codes of the intermediate (0 / 1 negative / 2 clamped)."""
+    t = torch.as_tensor(x)
+    a = t.detach().cpu().double()
+    if b is not None:
+        a = a + torch.as_tensor(b).detach().cpu().double().reshape(1, -1, 1, 1)
+    z = upfirdn2d(a, fu, up=up, padding=padding, gain=up ** 2, flip_filter=flip_filter).numpy()
+    z = z * gain
+    neg = z < 0
+    z = np.where(neg, z * slope, z)
+    codes = neg.astype(np.uint8)
+    if clamp is not None:
+        big = np.abs(z) > clamp
+        z = np.clip(z, -clamp, clamp)
+        codes = np.where(big, np.uint8(2), codes)
+    y = upfirdn2d(torch.from_numpy(z), fd, down=down, flip_filter=flip_filter).to(t.dtype)
+    return (y, torch.from_numpy(codes)) if return_signs else y
+
+
+# ---------------------------------------------------------------------------------------------------
+# tri-plane sampling  (dnnlib/util.py:580-617 on top of ATen grid_sampler_2d, align_corners=False, zeros)
+# ---------------------------------------------------------------------------------------------------
+
+def unnormalize(coord, size):
+    """fp32 ((c + 1) * size - 1) / 2 with one rounding per operation (ATen grid_sampler_unnormalize)."""
+    c = np.asarray(coord, dtype=np.float32)
+    one = np.float32(1)
+    return ((c + one) * np.float32(size) - one) * np.float32(0.5)
+
+
+def triplane_taps(coords, H, W):
+    """Integer tap origins and in-bounds masks per plane: [M, 3, 3] = (ix0, iy0, mask nw|ne<<1|sw<<2|se<<3)."""
+    c = np.asarray(coords, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros([c.shape[0], 3, 3], dtype=np.int32)
+    for pl, (a, b) in enumerate(((0, 1), (1, 2), (0, 2))):
+        u, v = unnormalize(c[:, a], W), unnormalize(c[:, b], H)
+        ix0 = np.clip(np.floor(u), -2, W + 1).astype(np.int32)
+        iy0 = np.clip(np.floor(v), -2, H + 1).astype(np.int32)
+        x0, x1 = (ix0 >= 0) & (ix0 < W), (ix0 + 1 >= 0) & (ix0 + 1 < W)
+        y0, y1 = (iy0 >= 0) & (iy0 < H), (iy0 + 1 >= 0) & (iy0 + 1 < H)
+        mask = (x0 & y0) * 1 + (x1 & y0) * 2 + (x0 & y1) * 4 + (x1 & y1) * 8
+        out[:, pl, 0], out[:, pl, 1], out[:, pl, 2] = ix0, iy0, mask
+    return out
+
+
+def sample_from_triplane(coordinates, grid):
+    """coordinates [B, M, 3], grid [B, 3C, H, W] -> [B*M, C]; bilinear taps accumulated in float64."""
+    co = torch.as_tensor(coordinates).detach().cpu().float().numpy()
+    g = torch.as_tensor(grid).detach().cpu().double().numpy()
+    B, C3, H, W = g.shape
+    C = C3 // 3
+    M = co.shape[1]
+    out = np.zeros([B, M, C])
+    for pl, (a, b) in enumerate(((0, 1), (1, 2), (0, 2))):
+        plane = g[:, pl * C:(pl + 1) * C]                       # [B, C, H, W]
+        u = unnormalize(co[..., a], W).astype(np.float64)
+        v = unnormalize(co[..., b], H).astype(np.float64)
+        x0 = np.floor(u)
+        y0 = np.floor(v)
+        for dy_, dx_ in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            xi, yi = x0 + dx_, y0 + dy_
+            wx = (x0 + 1 - u) if dx_ == 0 else (u - x0)
+            wy = (y0 + 1 - v) if dy_ == 0 else (v - y0)
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            xi_c = np.clip(xi, 0, W - 1).astype(np.int64)
+            yi_c = np.clip(yi, 0, H - 1).astype(np.int64)
+            for bi in range(B):
+                vals = plane[bi][:, yi_c[bi], xi_c[bi]]           # [C, M]
+                out[bi] += (vals * (wx[bi] * wy[bi] * ok[bi])[None, :]).T
+    return torch.from_numpy(out.reshape(B * M, C)).float()
+
+
+# ---------------------------------------------------------------------------------------------------
+# rays / cameras / compositing  (training/volumetric_rendering.py)
+# ---------------------------------------------------------------------------------------------------
+
+def camera_rays(fov, resolution):
+    """Unit ray directions [W*H, 3], x fastest, y flipped (volumetric_rendering.py:80-88)."""
+    W, H = resolution
+    xs = torch.linspace(-1, 1, W)
+    ys = torch.linspace(1, -1, H)
+    x = xs.repeat(H)                         # ray r = row * W + col -> x[col]
+    y = ys.repeat_interleave(W)
+    z = -torch.ones_like(x) / np.tan((2 * math.pi * fov / 360) / 2)
+    d = torch.stack([x, y, z], -1)
+    return d / torch.norm(d, dim=-1, keepdim=True)
+
+
+def initial_rays(n, num_steps, fov, resolution, ray_start, ray_end):
+    """volumetric_rendering.py:77-97 -> points [n,R,S,3], z_vals [n,R,S,1], rays_d_cam [n,R,3]."""
+    d = camera_rays(fov, resolution)
+    R = d.shape[0]
+    z = torch.linspace(ray_start, ray_end, num_steps)
+    z_vals = z.reshape(1, 1, num_steps, 1).expand(n, R, num_steps, 1).contiguous()
+    points = d.reshape(1, R, 1, 3) * z_vals
+    return points.contiguous(), z_vals, d.reshape(1, R, 3).expand(n, R, 3).contiguous()
+
+
+def perturb(points, z_vals, ray_directions, jitter):
+    """volumetric_rendering.py:99-105 with the U[0,1) draws supplied."""
+    step = z_vals[:, :, 1:2, :] - z_vals[:, :, 0:1, :]
+    offset = (jitter - 0.5) * step
+    return points + offset * ray_directions.unsqueeze(2), z_vals + offset
+
+
+def to_world(points, cam2world):
+    """p_world = cam2world @ [p, 1] (volumetric_rendering.py:123-127), float64 accumulate, fp32 result."""
+    R = cam2world[:, :3, :3].double()
+    t = cam2world[:, :3, 3].double()
+    shp = points.shape
+    p = points.reshape(shp[0], -1, 3).double()
+    return (torch.einsum('nij,nmj->nmi', R, p) + t[:, None, :]).float().reshape(shp)
+
+
+def camera_position(theta, phi, r):
+    """sample_camera_positions(mode=None) (volumetric_rendering.py:181-193)."""
+    phi = float(np.clip(np.float32(phi), 1e-5, math.pi - 1e-5))
+    th, ph = torch.tensor([[theta]], dtype=torch.float32), torch.tensor([[phi]], dtype=torch.float32)
+    pos = torch.zeros(1, 3)
+    pos[:, 0:1] = r * torch.sin(ph) * torch.cos(th)
+    pos[:, 2:3] = r * torch.sin(ph) * torch.sin(th)
+    pos[:, 1:2] = r * torch.cos(ph)
+    return pos
+
+
+def cam2world_lookat(forward, origin):
+    """create_cam2world_matrix (volumetric_rendering.py:195-213): R = [-left, up, -fwd] columns, T = origin."""
+    f = forward / forward.norm(dim=-1, keepdim=True)
+    up0 = torch.tensor([0., 1., 0.]).expand_as(f)
+    left = torch.linalg.cross(up0, f)
+    left = left / left.norm(dim=-1, keepdim=True)
+    up = torch.linalg.cross(f, left)
+    up = up / up.norm(dim=-1, keepdim=True)
+    n = f.shape[0]
+    m = torch.zeros(n, 4, 4)
+    m[:, :3, 0], m[:, :3, 1], m[:, :3, 2], m[:, :3, 3] = -left, up, -f, origin
+    m[:, 3, 3] = 1
+    return m
+
+
+def lookat_pose(h, v, lookat, radius):
+    """LookAtPoseSampler.sample with zero stddev (volumetric_rendering.py:278-295)."""
+    v = float(np.clip(np.float32(v), 1e-5, math.pi - 1e-5))
+    theta = torch.tensor([[h]], dtype=torch.float32)
+    phi = torch.arccos(1 - 2 * (torch.tensor([[v]], dtype=torch.float32) / math.pi))
+    o = torch.zeros(1, 3)
+    o[:, 0:1] = radius * torch.sin(phi) * torch.cos(theta)
+    o[:, 2:3] = radius * torch.sin(phi) * torch.sin(theta)
+    o[:, 1:2] = radius * torch.cos(phi)
+    return cam2world_lookat(torch.as_tensor(lookat, dtype=torch.float32).reshape(1, 3) - o, o)
+
+
+def composite(rgb_sigma, rays_d_cam, z_vals, noise=None, last_back=False, white_back=False, max_depth=None,
+              clamp_mode='softplus', fill_mode=None):
+    """fancy_integration (volumetric_rendering.py:34-74) with an explicit sequential loop over depth in float64.
+    rgb_sigma [N,R,S,C+1], rays_d_cam [N,R,3], z_vals [N,R,S,1], noise (already scaled) [N,R,S,1] or None."""
+    rs = rgb_sigma.double()
+    z = z_vals.double()
+    N, R, S, C1 = rs.shape
+    dn = torch.norm(rays_d_cam.float(), p=2, dim=-1, keepdim=True).double()       # [N,R,1]
+    sig = rs[..., -1]
+    if noise is not None:
+        sig = sig + noise.double()[..., 0]
+    if clamp_mode == 'softplus':
+        dens = torch.where(sig > 20, sig, torch.log1p(torch.exp(torch.clamp(sig, max=20))))
+    elif clamp_mode == 'relu':
+        dens = torch.clamp(sig, min=0)
+    else:
+        raise ValueError('Need to choose clamp mode')
+    T = torch.ones(N, R, dtype=torch.float64)
+    weights = torch.zeros(N, R, S, dtype=torch.float64)
+    for s in range(S):
+        delta = (z[:, :, s + 1, 0] - z[:, :, s, 0]) * dn[..., 0] if s + 1 < S else torch.full((N, R), 1e10, dtype=torch.float64)
+        alpha = 1 - torch.exp(-delta * dens[:, :, s])
+        weights[:, :, s] = alpha * T
+        T = T * (1 - alpha + 1e-10)
+    wsum = weights.sum(2)
+    if last_back:
+        weights[:, :, -1] += 1 - wsum
+    rgb = (weights[..., None] * rs[..., :-1]).sum(2)
+    depth = (weights * z[..., 0]).sum(2, keepdim=False)[..., None]
+    if white_back:
+        rgb = rgb + 1 - wsum[..., None]
+    if max_depth:
+        depth = depth + (1 - wsum[..., None]) * max_depth
+    if fill_mode == 'debug':
+        rgb[wsum < 0.9] = torch.tensor([1., 0., 0.], dtype=torch.float64)
+    elif fill_mode == 'weight':
+        rgb = wsum[..., None].expand_as(rgb).clone()
+    return rgb.float(), depth.float(), weights[..., None].float()
+
+
+def sample_pdf_det(bins, weights, n_importance, eps=1e-5):
+    """sample_pdf(det=True) (volumetric_rendering.py:224-265), float32 like the reference."""
+    w = weights.float() + eps
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    K = weights.shape[1]
+    u = torch.linspace(0, 1, n_importance).expand(weights.shape[0], n_importance).contiguous()
+    out = torch.zeros_like(u)
+    for r in range(weights.shape[0]):
+        for i in range(n_importance):
+            idx = int(torch.searchsorted(cdf[r], u[r, i]))
+            lo, hi = max(idx - 1, 0), min(idx, K)
+            den = cdf[r, hi] - cdf[r, lo]
+            if den < eps:
+                den = torch.tensor(1.0)
+            out[r, i] = bins[r, lo] + (u[r, i] - cdf[r, lo]) / den * (bins[r, hi] - bins[r, lo])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# post-processing  (dnnlib/seg_tools.py:13-32,75-81; dnnlib/util.py:632-646; extract_shapes.py:74-96)
+# ---------------------------------------------------------------------------------------------------
+
+PALETTE = np.array([[0, 0, 0], [204, 0, 0], [76, 153, 0], [204, 204, 0], [51, 51, 255], [204, 0, 204], [0, 255, 255],
+                    [255, 204, 204], [102, 51, 0], [255, 0, 0], [102, 204, 0], [255, 255, 0], [0, 0, 153], [0, 0, 204],
+                    [255, 51, 153], [0, 204, 204], [0, 51, 0], [255, 153, 51], [0, 204, 0]], dtype=np.uint8)
+
+
+def frame_u8(img, seg, palette=PALETTE):
+    """uint8 [N, H, 2W, 3]: layout_grid's float->uint8 of the RGB image next to mask2color(seg)
+    (gen_videos.py:133-135 `image_seg` layout)."""
+    im = torch.as_tensor(img).detach().cpu().float()
+    rgb = (im * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    idx = torch.argmax(torch.as_tensor(seg).detach().cpu().float(), dim=1).numpy()
+    col = np.asarray(palette)[idx]
+    return np.concatenate([rgb, col], axis=2)
+
+
+def create_samples(N, voxel_origin=(0, 0, 0), cube_length=2.0):
+    """extract_shapes.create_samples (extract_shapes.py:74-96), including its float-division index quirk."""
+    origin = np.array(voxel_origin, dtype=np.float64) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    idx = torch.arange(0, N ** 3, dtype=torch.int64)
+    s = torch.zeros(N ** 3, 3)
+    s[:, 2] = (idx % N).float()
+    s[:, 1] = (idx.float() / N) % N
+    s[:, 0] = ((idx.float() / N) / N) % N
+    s[:, 0] = s[:, 0] * voxel_size + origin[2]
+    s[:, 1] = s[:, 1] * voxel_size + origin[1]
+    s[:, 2] = s[:, 2] * voxel_size + origin[0]
+    return s.unsqueeze(0)

@@ -1,0 +1,217 @@
+"""Host-side logic of the product on CPU (no GPU needed): the reference call surfaces dispatch to their PyTorch
+definitions for CPU tensors and must reproduce the reference-generated golden vectors; the C-ABI library loads and
+exports every symbol the header declares; a missing library is a hard error."""
+
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, filter_from, t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- boundary ------------------------------------------------------------------------------------------
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'ide3d_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ide3d_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from torch_utils import hip_plugin
+    path = hip_plugin.lib_path()
+    assert os.path.isfile(path), f'{path} missing: run __graft_entry__.build()'
+    lib = ctypes.CDLL(path)
+    declared = _header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/ide3d_hip.h but not exported'
+    assert set(hip_plugin.EXPORTED_SYMBOLS) == set(declared)
+    lib.ide3d_abi_version.restype = ctypes.c_int
+    lib.ide3d_build_arch.restype = ctypes.c_char_p
+    assert lib.ide3d_abi_version() == 1
+    assert lib.ide3d_build_arch() == b'gfx950'
+
+
+def test_ctypes_structs_match_header_layout():
+    """Field order of the ctypes mirrors == field order of the C structs."""
+    from torch_utils import hip_plugin
+    src = open(os.path.join(ROOT, 'include', 'ide3d_hip.h')).read()
+    for cname, cls in (('ide3d_upfirdn2d_params', hip_plugin._UpfirdnParams), ('ide3d_filtered_lrelu_params', hip_plugin._FlreluParams),
+                       ('ide3d_render_params', hip_plugin._RenderParams), ('ide3d_modconv_params', hip_plugin._ModconvParams)):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(','):
+                m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*(\[\d+\])?\s*$', part.strip())
+                names.append(m.group(1))
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    from torch_utils import hip_plugin
+    monkeypatch.setenv('IDE3D_HIP_LIB', '/nonexistent/libide3d_hip.so')
+    monkeypatch.setattr(hip_plugin, '_lib', None)
+    with pytest.raises(RuntimeError, match='not found'):
+        hip_plugin.load()
+
+
+def test_product_does_not_import_oracle():
+    """The product tree must never reference the oracle."""
+    overlay = os.path.join(ROOT, 'ide-3d_amd')
+    for dirpath, _dirs, files in os.walk(overlay):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt, os.path.join(dirpath, fn)
+
+
+# ---- op surfaces on CPU tensors -----------------------------------------------------------------------------
+
+def test_bias_act_cpu(golden):
+    from torch_utils.ops import bias_act
+    assert list(bias_act.activation_funcs) == ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+    assert [s.cuda_idx for s in bias_act.activation_funcs.values()] == list(range(1, 10))
+    for cfg, a in golden('bias_act'):
+        kw = {k: cfg[k] for k in ('alpha', 'gain', 'clamp') if k in cfg}
+        b = None if cfg.get('nobias') else t(a['in_b'])
+        y = bias_act.bias_act(t(a['in_x']), b, dim=cfg['dim'], act=cfg['act'], **kw)
+        assert_close(y, a['out_y'], rtol=1e-6, atol=1e-6, what=str(cfg))
+
+
+def test_upfirdn2d_cpu(golden):
+    from torch_utils.ops import upfirdn2d
+    for cfg, a in golden('upfirdn2d'):
+        if 'fspec' in cfg:
+            kw = {k: v for k, v in cfg.items() if k != 'fspec'}
+            y = upfirdn2d.upfirdn2d(t(a['in_x']), filter_from(a['in_f']), **kw)
+            assert_close(y, a['out_y'], rtol=1e-5, atol=1e-5, what=str(cfg))
+        elif 'helper' in cfg:
+            y = getattr(upfirdn2d, cfg['helper'])(t(a['in_x']), t(a['in_f']))
+            assert_close(y, a['out_y'], rtol=1e-5, atol=1e-6, what=cfg['helper'])
+        else:
+            assert_close(upfirdn2d.setup_filter(**cfg['setup_filter']), a['out_y'], rtol=1e-6, atol=1e-7, what=str(cfg))
+
+
+def test_filtered_lrelu_cpu(golden):
+    from torch_utils.ops import filtered_lrelu
+    for cfg, a in golden('filtered_lrelu'):
+        y = filtered_lrelu.filtered_lrelu(t(a['in_x']), fu=filter_from(a['in_fu']), fd=filter_from(a['in_fd']), b=t(a['in_b']), **cfg)
+        assert_close(y, a['out_y'], rtol=1e-5, atol=1e-5, what=str(cfg))
+
+
+def test_volumetric_cpu(golden):
+    from training import volumetric_rendering as vr
+    for cfg, a in golden('volumetric'):
+        fn = cfg['fn']
+        if fn == 'get_initial_rays_trig':
+            p, z, d = vr.get_initial_rays_trig(cfg['n'], cfg['num_steps'], 'cpu', cfg['fov'], tuple(cfg['resolution']), cfg['ray_start'], cfg['ray_end'])
+            assert_close(p, a['out_points'], rtol=0, atol=0, what='points')
+            assert_close(z, a['out_z'], rtol=0, atol=0, what='z')
+            assert_close(d, a['out_d'], rtol=0, atol=0, what='dirs')
+        elif fn == 'gen_images_pose':
+            cam, _, _ = vr.sample_camera_positions('cpu', n=1, r=2.7, horizontal_mean=cfg['yaw'] + math.pi / 2, vertical_mean=math.pi / 2, mode=None)
+            assert_close(vr.create_cam2world_matrix(-cam, cam, device='cpu'), a['out_c2w'], rtol=0, atol=1e-7, what='c2w')
+        elif fn == 'lookat':
+            c2w = vr.LookAtPoseSampler.sample(cfg['h'], cfg['v'], torch.tensor(cfg['lookat']), radius=cfg['radius'])
+            assert_close(c2w, a['out_c2w'], rtol=0, atol=1e-6, what='lookat')
+        elif fn == 'transform_sampled_points':
+            p, z, d = vr.get_initial_rays_trig(cfg['n'], cfg['num_steps'], 'cpu', cfg['fov'], tuple(cfg['resolution']), cfg['ray_start'], cfg['ray_end'])
+            tp, tz, td, to, _, _ = vr.transform_sampled_points(p, z, d, 'cpu', h_stddev=0, v_stddev=0, camera=t(a['in_c2w']), mode=None,
+                                                               jitter=t(a['in_jitter']))
+            assert_close(tp, a['out_points'], rtol=1e-6, atol=1e-6, what='world points')
+            assert_close(tz, a['out_z'], rtol=0, atol=0, what='z')
+            assert_close(td, a['out_dirs'], rtol=1e-6, atol=1e-7, what='dirs')
+            assert_close(to, a['out_origins'], rtol=1e-6, atol=1e-7, what='origins')
+        elif fn == 'fancy_integration':
+            kw = {k: cfg[k] for k in ('clamp_mode', 'last_back', 'white_back', 'max_depth', 'fill_mode') if k in cfg}
+            noise = t(a['in_noise']) if 'in_noise' in a else None
+            rgb, depth, w = vr.fancy_integration(t(a['in_rs']).clone(), t(a['in_d']), t(a['in_z']), 'cpu', noise_std=cfg.get('noise_std', 0),
+                                                 noise=noise, **kw)
+            assert_close(rgb, a['out_rgb'], rtol=1e-5, atol=1e-5, what=f'rgb {cfg}')
+            assert_close(depth, a['out_depth'], rtol=1e-5, atol=1e-5, what='depth')
+            assert_close(w, a['out_w'], rtol=1e-5, atol=1e-6, what='weights')
+        elif fn == 'sample_pdf':
+            s = vr.sample_pdf(t(a['in_bins']), t(a['in_w']), cfg['N_importance'], det=True)
+            assert_close(s, a['out_samples'], rtol=1e-6, atol=1e-6, what='sample_pdf')
+    with pytest.raises(ValueError):
+        vr.fancy_integration(torch.zeros(1, 1, 2, 4), torch.ones(1, 1, 3), torch.zeros(1, 1, 2, 1), 'cpu', noise_std=0, clamp_mode=None)
+
+
+def test_triplane_cpu(golden):
+    from dnnlib import util
+    for cfg, a in golden('triplane'):
+        assert_close(util.sample_from_triplane(t(a['in_coords']), t(a['in_grid'])), a['out_feat'], rtol=1e-6, atol=1e-6, what=str(cfg))
+
+
+def test_networks_cpu(golden):
+    from training import networks
+    from torch_utils.ops import upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    for cfg, a in golden('networks').select(fn='modulated_conv2d'):
+        kw = {k: cfg[k] for k in ('up', 'padding', 'demodulate', 'fused_modconv', 'flip_weight')}
+        y = networks.modulated_conv2d(x=t(a['in_x']), weight=t(a['in_w']), styles=t(a['in_s']), noise=t(a['in_noise']),
+                                      resample_filter=(f if cfg['up'] > 1 else None), **kw)
+        assert_close(y, a['out_y'], rtol=1e-4, atol=1e-5, what=str(cfg))
+    (cfg, a), = golden('networks').select(fn='mapping')
+    m = networks.MappingNetwork(z_dim=16, c_dim=25, w_dim=12, num_ws=5, num_layers=3).eval()
+    m.load_state_dict({k[len('sd_mapping.'):]: t(v) for k, v in a.items() if k.startswith('sd_mapping.')})
+    with torch.no_grad():
+        assert_close(m(t(a['in_z']), t(a['in_c'])), a['out_ws'], rtol=1e-5, atol=1e-6, what='mapping')
+        assert_close(m(t(a['in_z']), t(a['in_c']), truncation_psi=0.6, truncation_cutoff=3), a['out_ws_trunc'], rtol=1e-5, atol=1e-6, what='trunc')
+
+
+def load_golden_generator(golden, device='cpu'):
+    from training import triplane
+    (cfg, a), = golden('generator_tiny').cases
+    G = triplane.TriPlaneGenerator(triplane.tiny_spec()).eval()
+    sd = {k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')}
+    missing, unexpected = G.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return G.to(device), cfg, a
+
+
+def test_generator_matches_reference_assembly_cpu(golden):
+    """Product generator (CPU path) == the same topology assembled from the reference's own modules."""
+    G, cfg, a = load_golden_generator(golden)
+    assert G.num_ws == a['out_ws'].shape[1] and G.synthesis.num_ws == G.num_ws
+    with torch.no_grad():
+        ws = G.mapping(t(a['in_z']), t(a['in_c_cond']), truncation_psi=cfg['truncation_psi'])
+        assert_close(ws, a['out_ws'], rtol=1e-5, atol=1e-6, what='ws')
+        out = G.synthesis(t(a['out_ws']), c=t(a['in_c']), noise_mode='const', ray_jitter=t(a['in_jitter']), return_dict=True)
+    assert_close(out['planes'][0], a['out_img_v'], rtol=1e-4, atol=1e-4, what='texture tri-plane')
+    assert_close(out['planes'][1], a['out_seg_v'], rtol=1e-4, atol=1e-4, what='semantic tri-plane')
+    assert_close(out['image_depth'], a['out_depth'], rtol=1e-5, atol=1e-5, what='depth')
+    assert_close(out['image'], a['out_img'], rtol=1e-3, atol=1e-3, what='image')
+    assert_close(out['image_seg'], a['out_seg'], rtol=1e-3, atol=1e-3, what='seg')
+    # driver-facing attributes
+    syn = G.synthesis
+    assert syn.voxel_block_resolutions == [4, 8, 16, 32] and syn.block_resolutions == [32, 64] and syn.render_size == 8
+    assert syn.vb4.num_conv == 1 and syn.vb8.num_conv == 2 and syn.vb8.num_torgb == 1
+    with torch.no_grad():
+        sv = syn.renderer.sample_voxel(t(a['out_img_v']), t(a['out_seg_v']), t(a['in_sample_pts']))
+    assert_close(sv, a['out_sample_out'], rtol=1e-4, atol=1e-5, what='sample_voxel')
+    img, seg = G.synthesis(t(a['out_ws']), c=t(a['in_c']), ray_jitter=t(a['in_jitter']), return_seg=True)
+    assert img.shape == (2, 3, 64, 64) and seg.shape == (2, 5, 64, 64)
+
+
+def test_full_spec_shapes():
+    from training import triplane
+    sp = triplane.GeneratorSpec()
+    assert sp.voxel_resolutions() == [4, 8, 16, 32, 64, 128, 256]
+    assert [sp.voxel_width(r) for r in sp.voxel_resolutions()] == [512, 512, 512, 512, 512, 256, 128]
+    assert sp.sr_resolutions() == [256, 512] and sp.sr_widths() == {256: 128, 512: 64}
+    c = triplane.conditioning_label()
+    assert c.shape == (1, 25) and float(c[0, 11]) == pytest.approx(2.7)
+    assert_close(triplane.camera_label(0.0)[:, :16], c[:, :16], rtol=0, atol=1e-6, what='frontal pose == conditioning pose')
