@@ -1,0 +1,359 @@
+"""Parity of the HIP kernels (through the C ABI, behind the reference call surfaces) against the reference-generated
+golden vectors and the CPU oracle.  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances (fp32 unless stated): element-wise ops 2e-6 abs/rel; FIR / interpolation sums 1e-5; compositing 2e-5;
+fp16 / bf16 storage 2e-3 / 2e-2 relative; tri-plane tap indices and in-bounds masks bit-exact.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fast_ops
+from oracle import ops as oracle_ops
+from util import assert_close, filter_from, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _native_calls():
+    from torch_utils import hip_plugin
+    hip_plugin.CALLS.clear()
+    yield hip_plugin.CALLS
+
+
+def _calls(name):
+    from torch_utils import hip_plugin
+    return hip_plugin.CALLS.get(name, 0)
+
+
+# ---- bias_act ------------------------------------------------------------------------------------------------
+
+def test_bias_act_golden(golden, gpu_device):
+    from torch_utils.ops import bias_act
+    for cfg, a in golden('bias_act'):
+        kw = {k: cfg[k] for k in ('alpha', 'gain', 'clamp') if k in cfg}
+        b = None if cfg.get('nobias') else t(a['in_b'], gpu_device)
+        y = bias_act.bias_act(t(a['in_x'], gpu_device), b, dim=cfg['dim'], act=cfg['act'], **kw)
+        assert y.is_cuda
+        assert_close(y, a['out_y'], rtol=2e-6, atol=2e-6, what=str(cfg))
+    assert _calls('bias_act') >= 29
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2), (torch.float64, 1e-12)])
+def test_bias_act_dtypes_layouts_and_tails(gpu_device, dtype, tol):
+    from torch_utils.ops import bias_act
+    g = torch.Generator().manual_seed(0)
+    for shape, cl in (((3, 5, 17, 13), False), ((2, 8, 9, 7), True), ((1, 3, 1, 1), False), ((4, 64, 32, 32), False)):
+        x = torch.randn(*shape, generator=g).to(dtype)
+        b = torch.randn(shape[1], generator=g).to(dtype)
+        xd = x.to(gpu_device)
+        if cl:
+            xd = xd.contiguous(memory_format=torch.channels_last)
+        for act in ('lrelu', 'softplus', 'swish', 'linear'):
+            y = bias_act.bias_act(xd, b.to(gpu_device), act=act, clamp=1.5)
+            ref = oracle_ops.bias_act(x.double(), b.double(), act=act, clamp=1.5)
+            assert y.stride() == xd.stride() and y.dtype == dtype
+            assert_close(y.double(), ref, rtol=tol, atol=tol, what=f'{dtype} {shape} {act}')
+
+
+def test_bias_act_gradients(gpu_device):
+    """First and second order gradients of the HIP op == autograd through the PyTorch definition."""
+    from torch_utils.ops import bias_act
+    g = torch.Generator().manual_seed(1)
+    for act in bias_act.activation_funcs:
+        x = torch.randn(2, 4, 6, 5, generator=g, dtype=torch.float64)
+        b = torch.randn(4, generator=g, dtype=torch.float64)
+        outs = []
+        for dev, impl in ((gpu_device, 'cuda'), ('cpu', 'ref')):
+            xx = x.to(dev).requires_grad_(True); bb = b.to(dev).requires_grad_(True)
+            y = bias_act.bias_act(xx, bb, act=act, gain=1.3, clamp=2.0, impl=impl)
+            w = torch.cos(torch.arange(y.numel(), dtype=torch.float64, device=dev)).reshape(y.shape)
+            gx, gb = torch.autograd.grad((y * w).sum(), [xx, bb], create_graph=True)
+            spec = bias_act.activation_funcs[act]
+            if spec.has_2nd_grad:
+                ggx, = torch.autograd.grad((gx * w).sum(), [xx], allow_unused=True)
+            else:
+                ggx = None
+            outs.append((y, gx, gb, ggx))
+        for name, a_, b_ in zip(('y', 'dx', 'db', 'd2x'), outs[0], outs[1]):
+            if a_ is None or b_ is None:
+                continue
+            assert_close(a_, b_, rtol=1e-9, atol=1e-9, what=f'{act} {name}')
+    assert _calls('bias_act') > 20
+
+
+# ---- upfirdn2d -------------------------------------------------------------------------------------------------
+
+def test_upfirdn2d_golden(golden, gpu_device):
+    from torch_utils.ops import upfirdn2d
+    for cfg, a in golden('upfirdn2d'):
+        if 'fspec' in cfg:
+            kw = {k: v for k, v in cfg.items() if k != 'fspec'}
+            f = filter_from(a['in_f'])
+            y = upfirdn2d.upfirdn2d(t(a['in_x'], gpu_device), None if f is None else f.to(gpu_device), **kw)
+            assert_close(y, a['out_y'], rtol=1e-5, atol=1e-5, what=str(cfg))
+        elif 'helper' in cfg:
+            y = getattr(upfirdn2d, cfg['helper'])(t(a['in_x'], gpu_device), t(a['in_f'], gpu_device))
+            assert_close(y, a['out_y'], rtol=1e-5, atol=1e-6, what=cfg['helper'])
+    assert _calls('upfirdn2d') >= 14
+
+
+@pytest.mark.parametrize('shape,kw', [
+    ((2, 3, 65, 65), dict(up=1, padding=[1, 1, 1, 1], gain=4)),            # after a transposed conv (odd width)
+    ((2, 5, 32, 32), dict(up=2, padding=[2, 1, 2, 1], gain=4)),            # skip-image upsample
+    ((1, 4, 70, 38), dict(up=2, padding=[3, 0, 1, 2], gain=1)),            # odd pads: shifted polyphase cells
+    ((1, 4, 64, 48), dict(down=2, padding=[1, 1, 1, 1])),
+    ((1, 2, 300, 200), dict(up=1, padding=[2, 1, 2, 1], flip_filter=True)),
+    ((1, 2, 40, 300), dict(up=2, padding=[2, 1, 2, 1], flip_filter=True, gain=4)),
+])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.float16, 4e-3)])
+def test_upfirdn2d_tile_kernels(gpu_device, shape, kw, dtype, tol):
+    """The LDS-tiled polyphase kernels (4x4 filter) against the oracle, including tile-edge and odd-size cases."""
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g).to(dtype)
+    f = torch.tensor([[1., 2., 3., 4.], [0.5, 3., 3., 1.], [2., 3., 5., 1.], [1., 3., 3., 7.]]) / 40     # asymmetric
+    y = upfirdn2d.upfirdn2d(x.to(gpu_device), f.to(gpu_device), **kw)
+    ref = fast_ops.upfirdn2d(x.float(), f, **kw)
+    assert y.dtype == dtype
+    assert_close(y.float(), ref, rtol=tol, atol=tol, what=f'{shape} {kw}')
+
+
+def test_upfirdn2d_channels_last_and_f64(gpu_device):
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 20, 22, generator=g)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    ref = fast_ops.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
+    y = upfirdn2d.upfirdn2d(x.to(gpu_device).contiguous(memory_format=torch.channels_last), f.to(gpu_device), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert_close(y, ref, rtol=1e-5, atol=1e-5, what='channels_last')
+    y = upfirdn2d.upfirdn2d(x.double().to(gpu_device), f.to(gpu_device), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert_close(y, oracle_ops.upfirdn2d(x.double(), f, up=2, padding=[2, 1, 2, 1], gain=4), rtol=1e-12, atol=1e-12, what='f64')
+
+
+def test_upfirdn2d_gradient(gpu_device):
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(5)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    for kw in (dict(up=2, padding=[2, 1, 2, 1], gain=4), dict(down=2, padding=[1, 1, 1, 1]), dict(up=1, padding=[1, 1, 1, 1], gain=4)):
+        x = torch.randn(2, 3, 12, 10, generator=g)
+        grads = []
+        for dev in (gpu_device, 'cpu'):
+            xx = x.to(dev).requires_grad_(True)
+            y = upfirdn2d.upfirdn2d(xx, f.to(dev), **kw)
+            w = torch.sin(torch.arange(y.numel(), dtype=torch.float32, device=dev)).reshape(y.shape)
+            grads.append(torch.autograd.grad((y * w).sum(), xx)[0])
+        assert_close(grads[0], grads[1], rtol=1e-5, atol=1e-5, what=f'dx {kw}')
+
+
+# ---- filtered_lrelu ----------------------------------------------------------------------------------------------
+
+def test_filtered_lrelu_golden(golden, gpu_device):
+    from torch_utils.ops import filtered_lrelu
+    for cfg, a in golden('filtered_lrelu'):
+        fu, fd = filter_from(a['in_fu']), filter_from(a['in_fd'])
+        y = filtered_lrelu.filtered_lrelu(t(a['in_x'], gpu_device), fu=None if fu is None else fu.to(gpu_device),
+                                          fd=None if fd is None else fd.to(gpu_device), b=t(a['in_b'], gpu_device), **cfg)
+        assert_close(y, a['out_y'], rtol=1e-5, atol=1e-5, what=str(cfg))
+    assert _calls('filtered_lrelu') >= 5
+
+
+def test_filtered_lrelu_signs_and_backward(gpu_device):
+    """Sign tensor == oracle's 2-bit codes; backward through the sign tensor == autograd through the definition."""
+    from torch_utils import hip_plugin
+    from torch_utils.ops import filtered_lrelu, upfirdn2d
+    g = torch.Generator().manual_seed(6)
+    f = upfirdn2d.setup_filter([1, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 1], separable=True)
+    x = torch.randn(2, 3, 12, 11, generator=g)
+    b = torch.randn(3, generator=g)
+    kw = dict(up=2, down=2, padding=[9, 10, 9, 10], gain=1.3, slope=0.25, clamp=0.8)
+    # raw plugin call to look at the sign tensor
+    plug = hip_plugin.FilteredLReluPlugin
+    y, so, rc = plug.filtered_lrelu(x.to(gpu_device), f.to(gpu_device), f.to(gpu_device), b.to(gpu_device), torch.empty([0]),
+                                    2, 2, 9, 10, 9, 10, 0, 0, 1.3, 0.25, 0.8, False, True)
+    assert rc == 0
+    yo, codes = oracle_ops.filtered_lrelu(x, fu=f, fd=f, b=b, return_signs=True, **kw)
+    assert_close(y, yo, rtol=1e-5, atol=1e-5, what='y with sign write')
+    so = so.cpu().numpy()
+    H, Wc = codes.shape[2], codes.shape[3]
+    unpacked = np.stack([(so >> (2 * j)) & 3 for j in range(4)], axis=-1).reshape(so.shape[0], so.shape[1], so.shape[2], -1)
+    mism = (unpacked[:, :, :H, :Wc] != codes.numpy())
+    # codes can only differ where the intermediate is within rounding distance of 0 or of the clamp
+    assert mism.mean() < 1e-3
+    # gradients
+    grads = []
+    for dev, impl in ((gpu_device, 'cuda'), ('cpu', 'ref')):
+        xx = x.to(dev).requires_grad_(True); bb = b.to(dev).requires_grad_(True)
+        yy = filtered_lrelu.filtered_lrelu(xx, fu=f.to(dev), fd=f.to(dev), b=bb, impl=impl, **kw)
+        w = torch.sin(torch.arange(yy.numel(), dtype=torch.float32, device=dev)).reshape(yy.shape)
+        grads.append(torch.autograd.grad((yy * w).sum(), [xx, bb]))
+    assert_close(grads[0][0], grads[1][0], rtol=1e-4, atol=1e-4, what='dx')
+    assert_close(grads[0][1], grads[1][1], rtol=1e-4, atol=1e-3, what='db')
+
+
+def test_filtered_lrelu_generic_fallback_path(gpu_device):
+    """`return_code = -1` route: upfirdn2d -> filtered_lrelu_act_ -> upfirdn2d (float64 has no fused kernel)."""
+    from torch_utils.ops import filtered_lrelu, upfirdn2d
+    g = torch.Generator().manual_seed(7)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    x = torch.randn(1, 2, 9, 9, generator=g, dtype=torch.float64)
+    b = torch.randn(2, generator=g, dtype=torch.float64)
+    kw = dict(up=2, down=1, padding=[2, 1, 2, 1], clamp=0.7)
+    with pytest.warns(RuntimeWarning):
+        y = filtered_lrelu.filtered_lrelu(x.to(gpu_device), fu=f.to(gpu_device), fd=f.to(gpu_device), b=b.to(gpu_device), **kw)
+    assert_close(y, oracle_ops.filtered_lrelu(x, fu=f, fd=f, b=b, **kw), rtol=1e-10, atol=1e-10, what='generic path')
+    assert _calls('filtered_lrelu_act_') == 1
+
+
+# ---- tri-plane gather ------------------------------------------------------------------------------------------------
+
+def test_triplane_golden_and_layouts(golden, gpu_device):
+    from dnnlib import util
+    for cfg, a in golden('triplane'):
+        grid, co = t(a['in_grid'], gpu_device), t(a['in_coords'], gpu_device)
+        for g_ in (grid, grid.contiguous(memory_format=torch.channels_last)):
+            out = util.sample_from_triplane(co, g_)
+            assert_close(out, a['out_feat'], rtol=1e-5, atol=2e-6, what=str(cfg))
+    assert _calls('triplane_sample') == 6
+
+
+def test_triplane_tap_indices_bit_exact(gpu_device):
+    """Integer tap origins and in-bounds masks equal the oracle's (== ATen's, tests/test_oracle_golden.py)."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(8)
+    co = (torch.rand(200000, 3, generator=g) * 2 - 1) * 1.05
+    co[:8] = torch.tensor([[1, -1, 0], [-1, 1, 1], [0.999999, -0.999999, 0.5], [1.0000001, 0, 0], [-1.0000001, 0, 0],
+                           [float('nan'), 0, 0], [float('inf'), 0, 0], [1e30, -1e30, 0]])
+    for H in (256, 37):
+        taps = hip_plugin.TriplanePlugin.taps(H, H, co.to(gpu_device)).cpu().numpy()
+        ref = oracle_ops.triplane_taps(np.nan_to_num(co.numpy(), nan=1e9, posinf=1e9, neginf=-1e9), H, H)
+        finite = np.isfinite(co.numpy()).all(axis=1)
+        assert np.array_equal(taps[finite], ref[finite])
+        assert (taps[~finite][:, 0, 2] == 0).all()          # non-finite coordinates never touch memory
+
+
+def test_triplane_full_size_properties(gpu_device):
+    """At the benchmark size (C=32, 256^2, M=393216): linearity in the planes and exactness on constant planes."""
+    from dnnlib import util
+    g = torch.Generator(device='cpu').manual_seed(9)
+    n, C, H, M = 1, 32, 256, 64 * 64 * 96
+    p1 = torch.randn(n, 3 * C, H, H, generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last)
+    p2 = torch.randn(n, 3 * C, H, H, generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last)
+    co = ((torch.rand(n, M, 3, generator=g) * 2 - 1) * 0.7).to(gpu_device)
+    o1, o2, o12 = util.sample_from_triplane(co, p1), util.sample_from_triplane(co, p2), util.sample_from_triplane(co, p1 + 2 * p2)
+    assert_close(o12, o1 + 2 * o2, rtol=1e-5, atol=2e-5, what='linearity')
+    const = torch.ones_like(p1) * 0.25
+    assert_close(util.sample_from_triplane(co, const), torch.full((M, C), 0.75), rtol=0, atol=1e-6, what='constant planes')
+    # subset against the oracle
+    idx = torch.arange(0, M, 997, device=gpu_device)
+    ref = fast_ops.sample_from_triplane(co[:, idx].cpu(), p1.cpu().contiguous())
+    assert_close(o1[idx], ref, rtol=1e-5, atol=2e-5, what='subset vs oracle')
+
+
+def test_triplane_backward(gpu_device):
+    from dnnlib import util
+    g = torch.Generator().manual_seed(10)
+    grid = torch.randn(2, 3 * 8, 16, 16, generator=g)
+    co = (torch.rand(2, 50, 3, generator=g) * 2 - 1) * 1.1
+    res = []
+    for dev in (gpu_device, 'cpu'):
+        gg = grid.to(dev).requires_grad_(True); cc = co.to(dev).requires_grad_(True)
+        out = util.sample_from_triplane(cc, gg)
+        w = torch.sin(torch.arange(out.numel(), dtype=torch.float32, device=dev)).reshape(out.shape)
+        res.append(torch.autograd.grad((out * w).sum(), [gg, cc]))
+    assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5, what='d planes')
+    assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-4, what='d coords')
+    assert _calls('triplane_sample_backward') == 1
+
+
+# ---- compositing -----------------------------------------------------------------------------------------------------
+
+def test_fancy_integration_golden(golden, gpu_device):
+    from training import volumetric_rendering as vr
+    cases = golden('volumetric').select(fn='fancy_integration')
+    for cfg, a in cases:
+        kw = {k: cfg[k] for k in ('clamp_mode', 'last_back', 'white_back', 'max_depth', 'fill_mode') if k in cfg}
+        noise = t(a['in_noise'], gpu_device) if 'in_noise' in a else None
+        with torch.no_grad():
+            rgb, depth, w = vr.fancy_integration(t(a['in_rs'], gpu_device), t(a['in_d'], gpu_device), t(a['in_z'], gpu_device), gpu_device,
+                                                 noise_std=cfg.get('noise_std', 0), noise=noise, **kw)
+        assert_close(w, a['out_w'], rtol=2e-5, atol=1e-6, what=f'weights {cfg}')
+        assert_close(rgb, a['out_rgb'], rtol=2e-5, atol=2e-5, what=f'rgb {cfg}')
+        assert_close(depth, a['out_depth'], rtol=2e-5, atol=2e-5, what=f'depth {cfg}')
+    assert _calls('composite') == len(cases)
+
+
+def test_fancy_integration_96_steps_52_channels(gpu_device):
+    from training import volumetric_rendering as vr
+    g = torch.Generator().manual_seed(11)
+    rs = torch.randn(2, 300, 96, 52, generator=g); rs[..., -1] *= 3
+    z = torch.sort(torch.rand(2, 300, 96, 1, generator=g) * 1.05 + 2.25, dim=2)[0]
+    d = torch.randn(2, 300, 3, generator=g)
+    with torch.no_grad():
+        rgb, depth, w = vr.fancy_integration(rs.to(gpu_device), d.to(gpu_device), z.to(gpu_device), gpu_device, noise_std=0, clamp_mode='softplus')
+    r_rgb, r_depth, r_w = oracle_ops.composite(rs, d, z)
+    assert_close(w, r_w, rtol=2e-5, atol=1e-6, what='weights')
+    assert_close(rgb, r_rgb, rtol=2e-5, atol=2e-5, what='rgb')
+    assert_close(depth, r_depth, rtol=2e-5, atol=2e-5, what='depth')
+    # a fully opaque ray integrates to weight sum 1 (partition of unity)
+    rs2 = rs.clone(); rs2[..., -1] = 50.0
+    with torch.no_grad():
+        _, _, w2 = vr.fancy_integration(rs2.to(gpu_device), d.to(gpu_device), z.to(gpu_device), gpu_device, noise_std=0, clamp_mode='relu')
+    assert_close(w2.sum(2), torch.ones(2, 300, 1), rtol=0, atol=1e-5, what='weights sum to one')
+
+
+# ---- modulated convolution (fp32 MFMA implicit GEMM) ---------------------------------------------------------------------
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k', [(2, 8, 16, 4, 4, 3), (1, 20, 150, 19, 33, 3), (3, 32, 96, 16, 16, 1), (2, 64, 3, 40, 24, 1),
+                                            (1, 128, 128, 32, 32, 3), (2, 6, 19, 9, 70, 1)])
+def test_modconv2d_against_conv2d(gpu_device, n, cin, cout, h, w, k):
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g)
+    s = torch.randn(n, cin, generator=g) + 1
+    noise = torch.randn(h, w, generator=g)
+    bias = torch.randn(cout, generator=g)
+    wmod = wt[None] * s[:, None, :, None, None]
+    d = (wmod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    ref = torch.cat([torch.nn.functional.conv2d(x[i:i + 1].double(), (wmod[i] * d[i][:, None, None, None]).double(), padding=k // 2) for i in range(n)])
+    ref = ref + 0.3 * noise.double() + bias.double()[None, :, None, None]
+    ref = torch.where(ref > 0, ref, ref * 0.2) * math.sqrt(2)
+    ref = ref.clamp(-3.0, 3.0)
+    y = hip_plugin.ModconvPlugin.modconv2d(x.to(gpu_device), wt.to(gpu_device), s.to(gpu_device), d.to(gpu_device), noise.to(gpu_device), 0.3,
+                                           bias.to(gpu_device), 3, 0.2, math.sqrt(2), 3.0)
+    scale = float(ref.abs().max())
+    assert_close(y, ref.float(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), what=f'modconv {n, cin, cout, h, w, k}')
+
+
+def test_modulated_conv2d_surface(golden, gpu_device):
+    from training import networks
+    from torch_utils.ops import upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(gpu_device)
+    with torch.no_grad():
+        for cfg, a in golden('networks').select(fn='modulated_conv2d'):
+            kw = {k: cfg[k] for k in ('up', 'padding', 'demodulate', 'fused_modconv', 'flip_weight')}
+            y = networks.modulated_conv2d(x=t(a['in_x'], gpu_device), weight=t(a['in_w'], gpu_device), styles=t(a['in_s'], gpu_device),
+                                          noise=t(a['in_noise'], gpu_device), resample_filter=(f if cfg['up'] > 1 else None), **kw)
+            assert_close(y, a['out_y'], rtol=1e-4, atol=1e-4, what=str(cfg))
+    assert _calls('modconv2d') >= 3
+
+
+# ---- frame conversion ------------------------------------------------------------------------------------------------------
+
+def test_frame_u8(golden, gpu_device):
+    from torch_utils import hip_plugin
+    (cfg, a), = golden('post').select(fn='frame')
+    pal = torch.from_numpy(oracle_ops.PALETTE).to(gpu_device)
+    out = hip_plugin.FramePlugin.frame_u8(t(a['in_img'], gpu_device), t(a['in_seg'], gpu_device), pal).cpu().numpy()
+    grid = np.concatenate([out[0], out[1]], axis=1)
+    assert np.array_equal(grid, a['out_grid_u8'])
+    g = torch.Generator().manual_seed(13)
+    img = torch.randn(3, 3, 64, 128, generator=g); seg = torch.randn(3, 19, 64, 128, generator=g)
+    out = hip_plugin.FramePlugin.frame_u8(img.to(gpu_device), seg.to(gpu_device), pal).cpu().numpy()
+    assert np.array_equal(out, oracle_ops.frame_u8(img, seg))

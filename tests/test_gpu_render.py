@@ -1,0 +1,167 @@
+"""Parity of the fused ray-marcher and of the whole generator on the GPU against the reference-generated golden
+vectors (tiny configuration) and the CPU oracle (full `ide3d-ffhq-64-512` configuration).  `pytest -m gpu`.
+
+Tolerances: renderer outputs 2e-4 relative to the feature scale (fp32 MFMA MLP + fast exp/log in softplus);
+full generator images 2e-3 relative to the image scale (hundreds of fp32 convolutions with different summation order).
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fast_ops
+from oracle import generator as ogen
+from oracle import ops as oracle_ops
+from oracle import spec as ospec
+from util import assert_close, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _calls(name):
+    from torch_utils import hip_plugin
+    return hip_plugin.CALLS.get(name, 0)
+
+
+def _rel(actual, expected, tol, what):
+    a = actual.detach().cpu().double(); e = torch.as_tensor(expected).double()
+    scale = float(e.abs().max()) + 1e-12
+    err = float((a - e).abs().max())
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol} * scale {scale:.3e}'
+
+
+def _load(golden, device):
+    from training import triplane
+    (cfg, a), = golden('generator_tiny').cases
+    G = triplane.TriPlaneGenerator(triplane.tiny_spec()).eval()
+    G.load_state_dict({k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')})
+    return G.to(device), cfg, a
+
+
+def test_fused_renderer_tiny_vs_reference(golden, gpu_device):
+    from torch_utils import hip_plugin
+    hip_plugin.CALLS.clear()
+    G, cfg, a = _load(golden, gpu_device)
+    cam = t(a['in_c'], gpu_device)[:, :16].reshape(-1, 4, 4)
+    with torch.no_grad():
+        feat, depth, wsum = G.synthesis.renderer(t(a['out_img_v'], gpu_device), t(a['out_seg_v'], gpu_device), cam,
+                                                 jitter=t(a['in_jitter'], gpu_device))
+    assert _calls('render_rays') == 1, 'the fused HIP kernel must have run'
+    _rel(feat, a['out_feat'], 2e-4, 'composited features')
+    _rel(depth, a['out_depth'], 1e-4, 'depth')
+    with torch.no_grad():
+        sv = G.synthesis.renderer.sample_voxel(t(a['out_img_v'], gpu_device), t(a['out_seg_v'], gpu_device), t(a['in_sample_pts'], gpu_device))
+        sig = G.synthesis.renderer.sample_voxel(t(a['out_img_v'], gpu_device), t(a['out_seg_v'], gpu_device), t(a['in_sample_pts'], gpu_device),
+                                                sigma_only=True)
+    assert _calls('sample_voxel') == 2
+    _rel(sv, a['out_sample_out'], 2e-4, 'sample_voxel')
+    _rel(sig, a['out_sample_out'][:, -1], 2e-4, 'sample_voxel sigma_only')
+
+
+def test_generator_tiny_vs_reference(golden, gpu_device):
+    G, cfg, a = _load(golden, gpu_device)
+    with torch.no_grad():
+        ws = G.mapping(t(a['in_z'], gpu_device), t(a['in_c_cond'], gpu_device), truncation_psi=cfg['truncation_psi'])
+        assert_close(ws, a['out_ws'], rtol=1e-4, atol=1e-5, what='ws')
+        out = G.synthesis(t(a['out_ws'], gpu_device), c=t(a['in_c'], gpu_device), noise_mode='const',
+                          ray_jitter=t(a['in_jitter'], gpu_device), return_dict=True)
+    _rel(out['planes'][0], a['out_img_v'], 2e-4, 'texture tri-plane')
+    _rel(out['planes'][1], a['out_seg_v'], 2e-4, 'semantic tri-plane')
+    _rel(out['image_depth'], a['out_depth'], 2e-4, 'depth')
+    _rel(out['image'], a['out_img'], 1e-3, 'image')
+    _rel(out['image_seg'], a['out_seg'], 1e-3, 'seg')
+    assert _calls('modconv2d') > 10 and _calls('upfirdn2d') > 5 and _calls('render_rays') >= 1
+
+
+def test_fused_renderer_full_size_vs_stepwise_and_oracle(gpu_device):
+    """C=32, hidden 64, 64x64 rays, 96 steps: fused kernel vs the step-wise HIP ops and (a ray subset) the CPU oracle."""
+    from training import triplane
+    from training import volumetric_rendering as vr
+    from dnnlib import util
+    torch.manual_seed(0)
+    sp = triplane.GeneratorSpec()
+    R = triplane.TriplaneRenderer(sp).to(gpu_device).eval()
+    with torch.no_grad():
+        for p in R.parameters():
+            if p.ndim == 1:
+                p.copy_(torch.randn_like(p) * 0.2)
+    g = torch.Generator().manual_seed(1)
+    n = 2
+    tex = (torch.randn(n, 96, 256, 256, generator=g) * 0.7).to(gpu_device)
+    geo = (torch.randn(n, 96, 256, 256, generator=g) * 0.7).to(gpu_device)
+    cam = torch.cat([triplane.camera_label(0.4), triplane.camera_label(-0.3, pitch=1.4)])[:, :16].reshape(-1, 4, 4).to(gpu_device)
+    jit = torch.rand(n, 4096, 96, generator=g).to(gpu_device)
+    with torch.no_grad():
+        feat, depth, wsum = R(tex, geo, cam, jitter=jit)
+        # step-wise on the GPU: reference-shaped pipeline on the individual HIP ops
+        pts, z, d = vr.get_initial_rays_trig(n, 96, gpu_device, sp.fov, (64, 64), sp.ray_start, sp.ray_end)
+        wp, z, _, _, _, _ = vr.transform_sampled_points(pts, z, d, gpu_device, h_stddev=0, v_stddev=0, camera=cam, mode=None, jitter=jit.unsqueeze(-1))
+        flat = wp.reshape(n, -1, 3)
+        out = R.decoder(util.sample_from_triplane(flat, tex), util.sample_from_triplane(flat, geo)).reshape(n, 4096, 96, -1)
+        f2, d2, w2 = vr.fancy_integration(out, d, z, gpu_device, noise_std=0, clamp_mode='softplus')
+    f2 = f2.permute(0, 2, 1).reshape(n, -1, 64, 64)
+    _rel(feat, f2, 3e-4, 'fused vs step-wise features')
+    _rel(depth, d2.permute(0, 2, 1).reshape(n, 1, 64, 64), 1e-4, 'fused vs step-wise depth')
+    _rel(wsum, w2.sum(2).permute(0, 2, 1).reshape(n, 1, 64, 64), 1e-4, 'weight sum')
+    # oracle on 64 rays of image 0
+    sd = {'synthesis.renderer.' + k: v.detach().cpu() for k, v in R.state_dict().items()}
+    osp = ospec.Spec()
+    rays = torch.arange(0, 4096, 64)
+    p0, z0, d0 = fast_ops.initial_rays(1, 96, osp.fov, (64, 64), osp.ray_start, osp.ray_end)
+    p0, z0, d0 = p0[:, rays], z0[:, rays], d0[:, rays]
+    p0, z0 = fast_ops.perturb(p0, z0, d0, jit[:1, rays].cpu().unsqueeze(-1))
+    w0 = fast_ops.to_world(p0, cam[:1].cpu())
+    o = ogen.sample_voxel(sd, osp, tex[:1].cpu(), geo[:1].cpu(), w0.reshape(1, -1, 3), fast_ops).reshape(1, len(rays), 96, -1)
+    fo, do, _ = fast_ops.composite(o, d0, z0)
+    got = feat[0].reshape(51, 4096)[:, rays].t()
+    _rel(got, fo[0], 3e-4, 'fused vs oracle features')
+    _rel(depth[0].reshape(4096)[rays], do[0, :, 0], 1e-4, 'fused vs oracle depth')
+
+
+def test_generator_full_size_vs_oracle(gpu_device):
+    """Random-init ide3d-ffhq-64-512 generator, one image: HIP path vs the CPU oracle (fp32 torch formulation)."""
+    from training import triplane
+    torch.manual_seed(0)
+    G = triplane.TriPlaneGenerator().eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(2)
+        for name, p in G.named_parameters():
+            if name.endswith('noise_strength'):
+                p.copy_(torch.randn([], generator=g) * 0.1)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    Gd = G.to(gpu_device)
+    z = torch.from_numpy(np.random.RandomState(0).randn(1, 512))
+    c = triplane.camera_label(0.5)
+    jit = torch.rand(1, 4096, 96, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ws = Gd.mapping(z.to(gpu_device), triplane.conditioning_label(gpu_device))
+        out = Gd.synthesis(ws, c=c.to(gpu_device), noise_mode='const', ray_jitter=jit.to(gpu_device), return_dict=True)
+    osp = ospec.Spec()
+    ws_o = ogen.mapping(sd, osp, z, triplane.conditioning_label(), ops=fast_ops)
+    _rel(ws, ws_o, 1e-4, 'ws')
+    ref = ogen.synthesis(sd, osp, ws_o, c, jitter=jit, ops=fast_ops)
+    _rel(out['planes'][0], ref['planes'][0], 1e-3, 'texture tri-plane')
+    _rel(out['planes'][1], ref['planes'][1], 1e-3, 'semantic tri-plane')
+    _rel(out['image_raw'], ref['image_raw'], 2e-3, 'raw 64x64 image')
+    _rel(out['image'], ref['image'], 2e-3, 'image 512')
+    _rel(out['image_seg'], ref['image_seg'], 2e-3, 'seg 512')
+    assert out['image'].shape == (1, 3, 512, 512) and out['image_seg'].shape == (1, 19, 512, 512)
+
+
+def test_extract_shapes_density_cube(golden, gpu_device):
+    """extract_shapes.py loop (:99-150) on a small lattice: chunked sigma-only queries == oracle."""
+    G, cfg, a = _load(golden, gpu_device)
+    N = 12
+    samples = (0.9 * oracle_ops.create_samples(N, cube_length=1.0)).to(gpu_device)
+    img_v, seg_v = t(a['out_img_v'], gpu_device)[:1], t(a['out_seg_v'], gpu_device)[:1]
+    sig = torch.zeros(1, N ** 3, device=gpu_device)
+    with torch.no_grad():
+        head, step = 0, 500
+        while head < N ** 3:
+            sig[:, head:head + step] = G.synthesis.renderer.sample_voxel(img_v, seg_v, samples[:, head:head + step], sigma_only=True).reshape(1, -1)
+            head += step
+    sd = {k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')}
+    ref = ogen.sample_voxel(sd, ospec.tiny(), img_v.cpu(), seg_v.cpu(), samples.cpu(), fast_ops)[:, -1]
+    _rel(sig[0], ref, 2e-4, 'sigma lattice')
