@@ -81,15 +81,14 @@ __device__ __forceinline__ float softplus_fast(float x) {
 
 // Gather this lane's NF features of one sample from one tri-plane (channels_last, channel stride 1).
 template <int C>
-__device__ __forceinline__ void gather_features(const float* __restrict__ pb, int64_t sH, int64_t sW,
-                                                const Tap2 (&t)[3], int g, float (&f)[C / 4]) {
+__device__ __forceinline__ void gather_features(const float* __restrict__ pb, const TapAddr (&t)[3], int g, float (&f)[C / 4]) {
     constexpr int CPL = C / 16;
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
         const int ch = 4 * (g + 4 * ci);
-        const float4 a0 = gather_plane_cl(pb + ch, sH, sW, t[0]);
-        const float4 a1 = gather_plane_cl(pb + C + ch, sH, sW, t[1]);
-        const float4 a2 = gather_plane_cl(pb + 2 * C + ch, sH, sW, t[2]);
+        const float4 a0 = gather_plane_cl(pb + ch, t[0]);
+        const float4 a1 = gather_plane_cl(pb + C + ch, t[1]);
+        const float4 a2 = gather_plane_cl(pb + 2 * C + ch, t[2]);
         f[4 * ci + 0] = (a0.x + a1.x) + a2.x;
         f[4 * ci + 1] = (a0.y + a1.y) + a2.y;
         f[4 * ci + 2] = (a0.z + a1.z) + a2.z;
@@ -173,6 +172,7 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     if (ray_end > total_rays) ray_end = total_rays;
     const int S = p.steps;
     const int nch = p.feat_ch + p.seg_ch;
+    const int sH = (int)p.tex_stride[2], sW = (int)p.tex_stride[3];   // host guarantees tex / geo share the layout
 
     for (int64_t ray = ray_begin + wid; ray < ray_end; ray += 4) {
         const int n = (int)(ray / p.rays_per_img);
@@ -214,13 +214,14 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
             const float wy = fmaf(m10, px, fmaf(m11, py, fmaf(m12, pz, m13)));
             const float wz = fmaf(m20, px, fmaf(m21, py, fmaf(m22, pz, m23)));
             // --- gathers ---
-            Tap2 t[3] = { make_tap(wx, wy, p.W, p.H), make_tap(wy, wz, p.W, p.H), make_tap(wx, wz, p.W, p.H) };
+            const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
+                                   make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
             float fg[K::NF], ft[K::NF];
             f32x4 og[2], ot[2];
-            gather_features<C>(geo_b, p.geo_stride[2], p.geo_stride[3], t, g, fg);
+            gather_features<C>(geo_b, t, g, fg);
             mlp_tile<C, HID>(s_geo, fg, og);
             asm volatile("" ::: "memory");     // keep the second gather behind the first MLP (register budget)
-            gather_features<C>(tex_b, p.tex_stride[2], p.tex_stride[3], t, g, ft);
+            gather_features<C>(tex_b, t, g, ft);
             mlp_tile<C, HID>(s_tex, ft, ot);
             // --- compositing weights ---
             float sigma = __shfl(og[0][0], j);                    // feature 0 lives in lanes g = 0
@@ -286,6 +287,7 @@ sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int width = p.feat_ch + p.seg_ch + 1;
+    const int sH = (int)p.tex_stride[2], sW = (int)p.tex_stride[3];
     float* stage = s_stage + wid * 16 * width;
     const int64_t rows = (int64_t)p.n * m;
     const int64_t ntiles = cdiv64(rows, 16);
@@ -300,9 +302,10 @@ sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_
         const int64_t rc = live ? row : rows - 1;
         const int n = (int)(rc / m);
         const float wx = pts[rc * 3 + 0], wy = pts[rc * 3 + 1], wz = pts[rc * 3 + 2];
-        Tap2 t[3] = { make_tap(wx, wy, p.W, p.H), make_tap(wy, wz, p.W, p.H), make_tap(wx, wz, p.W, p.H) };
+        const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
+                               make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
         float fg[K::NF];
-        gather_features<C>(p.geo_planes + n * p.geo_stride[0], p.geo_stride[2], p.geo_stride[3], t, g, fg);
+        gather_features<C>(p.geo_planes + n * p.geo_stride[0], t, g, fg);
         f32x4 og[2];
         mlp_tile<C, HID>(s_geo, fg, og);
         if (sigma_only) {
@@ -310,7 +313,7 @@ sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_
             continue;
         }
         float ft[K::NF];
-        gather_features<C>(p.tex_planes + n * p.tex_stride[0], p.tex_stride[2], p.tex_stride[3], t, g, ft);
+        gather_features<C>(p.tex_planes + n * p.tex_stride[0], t, g, ft);
         f32x4 ot[2];
         mlp_tile<C, HID>(s_tex, ft, ot);
         // stage the 16 x width row block, then write it out contiguously
@@ -387,7 +390,9 @@ static bool planes_fast(const ide3d_render_params& p) {
         return s[1] == 1 && (s[0] % 4 == 0) && (s[2] % 4 == 0) && (s[3] % 4 == 0) &&
                ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
     };
-    return ok(p.tex_planes, p.tex_stride) && ok(p.geo_planes, p.geo_stride);
+    return ok(p.tex_planes, p.tex_stride) && ok(p.geo_planes, p.geo_stride) &&
+           p.tex_stride[2] == p.geo_stride[2] && p.tex_stride[3] == p.geo_stride[3] &&
+           p.tex_stride[2] * p.H < 0x7fffffffLL && p.tex_stride[3] * p.W < 0x7fffffffLL;
 }
 
 }  // namespace ide3d

@@ -25,7 +25,7 @@ namespace ide3d {
 // Fast path: channels_last planes (stride of the channel axis == 1), C % 4 == 0, (C/4) | 64.
 template <int LPS>   // lanes per sample = C / 4
 __global__ void __launch_bounds__(256)
-triplane_sample_cl_kernel(const float* __restrict__ planes, int64_t sN, int64_t sH, int64_t sW,
+triplane_sample_cl_kernel(const float* __restrict__ planes, int64_t sN, int sH, int sW,
                           int C, int H, int W, const float* __restrict__ coords, int64_t m,
                           int64_t rows, float* __restrict__ out, int64_t rows_per_block) {
     constexpr int SPW = kWave / LPS;                     // samples per wave-iteration
@@ -34,23 +34,34 @@ triplane_sample_cl_kernel(const float* __restrict__ planes, int64_t sN, int64_t 
     const int64_t row_begin = (int64_t)blk * rows_per_block;
     int64_t row_end = row_begin + rows_per_block;
     if (row_end > rows) row_end = rows;
+    if (row_begin >= row_end) return;
     const int sub = threadIdx.x / LPS;                   // sample slot inside the workgroup
     const int cl = threadIdx.x % LPS;                    // 4-channel slice
-    for (int64_t row = row_begin + sub; row < row_end; row += SPB) {
-        const float* cp = coords + row * 3;
-        const float cx = cp[0], cy = cp[1], cz = cp[2];
-        const int64_t n = row / m;
-        const float* pb = planes + n * sN + cl * 4;
-        const Tap2 t0 = make_tap(cx, cy, W, H);
-        const Tap2 t1 = make_tap(cy, cz, W, H);
-        const Tap2 t2 = make_tap(cx, cz, W, H);
-        const float4 a0 = gather_plane_cl(pb, sH, sW, t0);
-        const float4 a1 = gather_plane_cl(pb + C, sH, sW, t1);
-        const float4 a2 = gather_plane_cl(pb + 2 * C, sH, sW, t2);
+    // image index of the current row, tracked incrementally (no 64-bit division in the loop)
+    int64_t n = row_begin / m;
+    int64_t n_end = (n + 1) * m;                         // first row of image n + 1
+    const float* pb = planes + n * sN + cl * 4;
+    // software-pipelined coordinate fetch: the next iteration's (x, y, z) is in flight during the gathers
+    int64_t row = row_begin + sub;
+    const int64_t last = row_end - 1;
+    const float* cp = coords + (row < last ? row : last) * 3;
+    float cx = cp[0], cy = cp[1], cz = cp[2];
+    for (; row < row_end; row += SPB) {
+        const int64_t nxt = row + SPB;
+        const float* np_ = coords + (nxt < last ? nxt : last) * 3;
+        const float ncx = np_[0], ncy = np_[1], ncz = np_[2];
+        while (row >= n_end) { n_end += m; pb += sN; }
+        const TapAddr t0 = make_tap_addr(cx, cy, W, H, sH, sW);
+        const TapAddr t1 = make_tap_addr(cy, cz, W, H, sH, sW);
+        const TapAddr t2 = make_tap_addr(cx, cz, W, H, sH, sW);
+        const float4 a0 = gather_plane_cl(pb, t0);
+        const float4 a1 = gather_plane_cl(pb + C, t1);
+        const float4 a2 = gather_plane_cl(pb + 2 * C, t2);
         float4 r;
         r.x = (a0.x + a1.x) + a2.x; r.y = (a0.y + a1.y) + a2.y;
         r.z = (a0.z + a1.z) + a2.z; r.w = (a0.w + a1.w) + a2.w;
-        *reinterpret_cast<float4*>(out + row * C + cl * 4) = r;
+        *reinterpret_cast<float4*>(__builtin_assume_aligned(out + row * C + cl * 4, 16)) = r;
+        cx = ncx; cy = ncy; cz = ncz;
     }
 }
 
@@ -187,7 +198,7 @@ static void launch_cl(const float* planes, const int64_t* s, int n, int C, int H
     if (rpb < SPB) rpb = SPB;
     nblk = cdiv64(rows, rpb);
     hipLaunchKernelGGL((triplane_sample_cl_kernel<LPS>), dim3((unsigned)nblk), dim3(256), 0, st,
-                       planes, s[0], s[2], s[3], C, H, W, coords, m, rows, out, rpb);
+                       planes, s[0], (int)s[2], (int)s[3], C, H, W, coords, m, rows, out, rpb);
 }
 
 }  // namespace ide3d
@@ -202,6 +213,7 @@ extern "C" int ide3d_triplane_sample(const float* planes, const int64_t plane_st
     hipStream_t st = (hipStream_t)stream;
     const int64_t* s = plane_stride;
     const bool cl = (s[1] == 1) && (C % 4 == 0) && (s[0] % 4 == 0) && (s[2] % 4 == 0) && (s[3] % 4 == 0) &&
+                    (s[2] > 0 && s[3] > 0 && s[2] * H < 0x7fffffffLL && s[3] * W < 0x7fffffffLL) &&
                     ((reinterpret_cast<uintptr_t>(planes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int lps = C / 4;
     if (cl && lps >= 1 && lps <= 64 && (64 % lps) == 0) {

@@ -1,0 +1,8 @@
+"""Run only the stand-alone tri-plane gather (benchmark shape) a few times — target for rocprofv3 PMC passes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'ide-3d_amd')); sys.path.insert(0, ROOT)
+import torch
+import bench
+r = bench.bench_gather(torch.device('cuda:0'), iters=int(sys.argv[1]) if len(sys.argv) > 1 else 10)
+print(r)

@@ -26,7 +26,7 @@ def _calls(name):
 
 
 def _rel(actual, expected, tol, what):
-    a = actual.detach().cpu().double(); e = torch.as_tensor(expected).double()
+    a = actual.detach().cpu().double(); e = torch.as_tensor(expected).detach().cpu().double()
     scale = float(e.abs().max()) + 1e-12
     err = float((a - e).abs().max())
     assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol} * scale {scale:.3e}'
