@@ -1,71 +1,175 @@
-// modconv.hip — StyleGAN2 modulated convolution as an fp32 MFMA implicit GEMM with fused epilogue.
+// modconv.hip — StyleGAN2 modulated convolutions as fp32-MFMA implicit GEMMs with fused epilogues.
 //
-// Replaces, for stride-1 k x k (k in {1, 3}) layers, the ATen conv behind
-// `conv2d_gradfix.conv2d` (torch_utils/ops/conv2d_gradfix.py:35) as used by `modulated_conv2d`
-// (inversion/networks.py:55-130) together with the epilogue of `SynthesisLayer.forward`
-// (networks.py:457-512: `+ noise`, `bias_act(lrelu, gain, clamp)`) and of `ToRGBLayer.forward`
-// (networks.py:700-707: no demodulation, linear, clamp):
-//   y[n,o,p] = act( d[n,o] * sum_{i,t} w[o,i,t] * s[n,i] * x[n,i,p+t] + ns*noise[p] + b[o] ) * gain
-// (the un-fused formulation of networks.py:99-114, which needs no per-sample weight tensor).
+// Replaces the ATen convolutions behind `conv2d_gradfix.conv2d / conv_transpose2d`
+// (torch_utils/ops/conv2d_gradfix.py:35,40) for the three shapes the generator uses, as called from
+// `modulated_conv2d` (inversion/networks.py:55-130) via `conv2d_resample` (conv2d_resample.py:112-134):
+//   mode 0  3x3, stride 1, pad 1 (correlation)          SynthesisLayer conv1 / up = 1
+//   mode 1  1x1                                         ToRGBLayer / toSeg heads
+//   mode 2  3x3 transposed, stride 2, pad 0 -> (2H+1)x(2W+1)   first half of an up-sampling SynthesisLayer
+//           (the 4x4 FIR that follows is csrc/upfirdn2d.hip)
+// with the un-fused modulation algebra of networks.py:99-114: the INPUT patch is scaled by the styles s[n,ci]
+// while it is staged, the weights are shared by the whole batch, demodulation d[n,co] is applied to the
+// accumulators, and (modes 0/1) noise + bias + leaky-ReLU + gain + clamp finish in registers
+// (networks.py:457-512, :700-707).
 //
-// GEMM view per image: M = cout, N = pixels, K = cin*k*k on v_mfma_f32_32x32x2_f32 (fp32 in, fp32
-// accumulate, exact fp32 products -> same numerics class as the reference's fp32 conv).
-//   * workgroup = 4 waves; output tile BM x 128 pixels (an 8 x 16 pixel patch); two shapes:
-//       BIG   BM = 128: waves 2(M) x 2(N), each 64 couts x 64 pixels  (4 accumulators of 32x32)
-//       SMALL BM = 32 : waves 1(M) x 4(N), each 32 couts x 32 pixels  (toRGB / toSeg heads)
-//   * K is walked in chunks of KC input channels: the chunk's weights are staged in LDS already
-//     multiplied by the styles (A operand, [k][cout] with a +1 pad -> conflict-free both ways), the
-//     chunk's input halo patch ((8+k-1) x (16+k-1) per channel, zero padded) is staged once and read
-//     k*k times with shifted addresses (B operand) — im2col never materialises;
-//   * epilogue in registers: demodulation, noise, bias, lrelu, gain, clamp, then NCHW stores.
-// The fp32 MFMA rate (157 TFLOP/s peak) bounds this kernel; LDS/L2 traffic is ~5 B/clk/CU.
+// GEMM view: M = cout, N = batch x pixels, K = cin x taps on v_mfma_f32_32x32x2_f32 (exact fp32 products).
+//   * 256-thread workgroup, BM x 128 output tile: BIG = 128 couts (waves 2 x 2, 4 accumulators each) or SMALL = 32
+//     couts (waves 1 x 4).  The 128 "pixels" of a tile are TI images x PH x PW (1x8x16, 2x8x8 or 8x4x4) so that
+//     low-resolution layers still fill the N dimension.
+//   * weights are pre-packed once per call into [m-block][k-chunk][tap][ci][co] (ide3d_modconv_pack): a K chunk is
+//     one contiguous slab copied with 16-byte loads and stored linearly in LDS (A operand, conflict-free);
+//   * the input halo patch ((PH+2) x (PW+2) per channel, zero padded, x style) is staged once per chunk and read
+//     once per tap with a shifted address (B operand): im2col never materialises;
+//   * transposed convolution: the four output parity classes (oy%2, ox%2) are separate tile sets, each walking
+//     only its own taps (4 / 2 / 2 / 1 of the 9), so no multiplications by inserted zeros are issued;
+//   * global -> register -> LDS double buffering: chunk c+1 is fetched while chunk c feeds the MFMAs, one barrier
+//     per chunk;
+//   * split-K (low-resolution 512-channel layers have too few tiles to fill 256 CUs): partial sums go to a
+//     workspace, `modconv_epilogue_kernel` reduces them and applies the epilogue — deterministic, no atomics.
+// Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
 #include "common.h"
 
 namespace ide3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS, int BIG>
+enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2 };
+
+template <int MODE> struct ModeCfg;
+template <> struct ModeCfg<MODE_CONV3>  { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
+template <> struct ModeCfg<MODE_CONV1>  { static constexpr int KC = 16, WTAPS = 1, MAXT = 1; };
+template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9, MAXT = 4; };
+
+template <int MODE, int BIG, int TI, int PH, int PW>
 struct McCfg {
-    static constexpr int PH = 8, PW = 16;                 // pixel patch (BN = 128)
-    static constexpr int WM = BIG ? 2 : 1;                // waves along M
-    static constexpr int WN = 4 / WM;                     // waves along N
-    static constexpr int MTW = BIG ? 2 : 1;               // 32-row M tiles per wave
-    static constexpr int NTW = (PH * PW / 32) / WN;       // 32-pixel N tiles per wave
+    static_assert(TI * PH * PW == 128, "pixel tile must hold 128 pixels");
+    using MC = ModeCfg<MODE>;
+    static constexpr int KC = MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
+    static constexpr int WM = BIG ? 2 : 1, WN = 4 / WM;
+    static constexpr int MTW = BIG ? 2 : 1;                 // 32-row M tiles per wave
+    static constexpr int NTW = 4 / WN;                      // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
-    static constexpr int KC = (KS == 3) ? 4 : 16;         // input channels per K chunk
-    static constexpr int TAPS = KS * KS;
-    static constexpr int KK = KC * TAPS;                  // K elements per chunk (even)
-    static constexpr int HP = PH + KS - 1, HW = PW + KS - 1;
-    static constexpr int XW = HW + 2;                     // LDS row pitch of the halo patch
-    static constexpr int XS = HP * XW;                    // per-channel pitch
-    static constexpr int WP = BM + 1;                     // LDS pitch of a weight k-row
-    static constexpr int LDS_W = KK * WP;
-    static constexpr int LDS_X = KC * XS;
+    static constexpr int HP = PH + 2, HW = PW + 2;          // halo patch
+    static constexpr int XW = HW + 2;                       // LDS row pitch
+    static constexpr int XS = HP * XW;                      // per-channel pitch
+    static constexpr int XI = KC * XS;                      // per-image pitch
+    static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
+    static constexpr int LDS_X = TI * XI;
+    static constexpr int NW4 = (LDS_W / 4 + 255) / 256;     // float4 weight loads per thread per chunk
+    static constexpr int NXE = (TI * KC * HP * HW + 255) / 256;   // input elements per thread per chunk
 };
 
-template <int KS, int BIG>
+template <int N>
+__device__ __forceinline__ int sel(const int (&a)[N], int t) {
+    int v = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = (t == i) ? a[i] : v;
+    return v;
+}
+
+__host__ __device__ inline int mc_bm(int cout) { return cout > 96 ? 128 : 32; }
+__host__ __device__ inline int mc_kc(int k) { return k == 3 ? 4 : 16; }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: w [cout, cin, k, k] -> [mb][cc][tap][cil][co]  (zero padded to full blocks)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+modconv_pack_kernel(const float* __restrict__ w, int cout, int cin, int taps, int bm, int kc, int mblocks, int cchunks,
+                    float* __restrict__ out) {
+    const int64_t total = (int64_t)mblocks * cchunks * taps * kc * bm;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int64_t r = i;
+        const int co_l = (int)(r % bm); r /= bm;
+        const int cil = (int)(r % kc); r /= kc;
+        const int tap = (int)(r % taps); r /= taps;
+        const int cc = (int)(r % cchunks); r /= cchunks;
+        const int mb = (int)r;
+        const int co = mb * bm + co_l, ci = cc * kc + cil;
+        out[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * taps + tap] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int tiles_x[4], tiles_y[4];     // per parity class (class 0 only for modes 0 / 1)
+    int tile_base[5];               // prefix sum of tiles per class (per image group)
+    int img_groups;                 // ceil(n / TI)
+    int mblocks, cchunks, split_k, chunks_per_split;
+    int oh, ow;                     // output size
+};
+
+template <int MODE, int BIG, int TI, int PH, int PW>
 __global__ void __launch_bounds__(256, 2)
-modconv_kernel(ide3d_modconv_params p, int tiles_x, int tiles_y, int mblocks) {
-    using K = McCfg<KS, BIG>;
-    __shared__ float s_w[K::LDS_W];
-    __shared__ float s_x[K::LDS_X];
+modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
+    using K = McCfg<MODE, BIG, TI, PH, PW>;
+    __shared__ __attribute__((aligned(16))) float s_w[2][K::LDS_W];
+    __shared__ __attribute__((aligned(16))) float s_x[2][K::LDS_X];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / K::WN, wn = wid % K::WN;
     const int half = lane >> 5, l32 = lane & 31;
 
+    // ---- block decomposition: ((split, img_group, tile), m-block) with m-block fastest (shares the input patch) ----
     int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mb = bid % mblocks; bid /= mblocks;
-    const int txi = bid % tiles_x; bid /= tiles_x;
-    const int tyi = bid % tiles_y; bid /= tiles_y;
-    const int n = bid;
-    const int co0 = mb * K::BM;
-    const int y0 = tyi * K::PH, x0 = txi * K::PW;
-    constexpr int PAD = KS / 2;
+    const int mb = bid % g.mblocks; bid /= g.mblocks;
+    const int tiles_per_group = g.tile_base[4];
+    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    const int grp = bid % g.img_groups; bid /= g.img_groups;
+    const int split = bid;
+    int cls = 0;
+    if (MODE == MODE_TCONV3) { cls = (tile >= g.tile_base[1]) + (tile >= g.tile_base[2]) + (tile >= g.tile_base[3]); }
+    const int tl = tile - g.tile_base[cls];
+    const int txi = tl % g.tiles_x[cls], tyi = tl / g.tiles_x[cls];
+    const int y0 = tyi * PH, x0 = txi * PW;                       // tile origin in (class-)grid coordinates
+    const int n0 = grp * TI;
+    const int cpy = cls >> 1, cpx = cls & 1;                      // output parity of this class (tconv)
 
-    const float* __restrict__ xin = p.x + (int64_t)n * p.cin * p.h * p.w_;
-    const float* __restrict__ sty = p.styles + (int64_t)n * p.cin;
+    // ---- tap table of this block: weight index and patch offsets (dy, dx) ----
+    int ntaps, t_widx[K::MAXT], t_off[K::MAXT];
+    if (MODE == MODE_CONV3) {
+        ntaps = 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { t_widx[t] = t; t_off[t] = (t / 3) * K::XW + (t % 3); }
+    } else if (MODE == MODE_CONV1) {
+        ntaps = 1; t_widx[0] = 0; t_off[0] = K::XW + 1;
+    } else {
+        // out[2i+ky] += x[i] w[ky]:  even output rows take ky = 0 (i = c) and ky = 2 (i = c-1); odd rows ky = 1 (i = c).
+        // patch row of input i for grid row c (patch origin = y0 - 1): (c - y0) + 1 + (i - c).
+        const int nky = cpy ? 1 : 2, nkx = cpx ? 1 : 2;
+        ntaps = nky * nkx;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int a = t / nkx, b = t % nkx;
+            const int ky = cpy ? 1 : (a == 0 ? 0 : 2), kx = cpx ? 1 : (b == 0 ? 0 : 2);
+            const int dy = (ky == 2) ? 0 : 1, dx = (kx == 2) ? 0 : 1;
+            t_widx[t] = ky * 3 + kx; t_off[t] = dy * K::XW + dx;
+        }
+    }
+
+    // ---- staging plan (fixed across chunks) ----
+    const float* __restrict__ wsrc = wp + (int64_t)mb * g.cchunks * (K::WTAPS * K::KC * K::BM);
+    int x_src[K::NXE], x_dst[K::NXE], x_img[K::NXE];
+#pragma unroll
+    for (int i = 0; i < K::NXE; ++i) {
+        const int e = tid + i * 256;
+        x_src[i] = -1; x_dst[i] = -1; x_img[i] = 0;
+        if (e < TI * K::KC * K::HP * K::HW) {
+            int r = e;
+            const int rx = r % K::HW; r /= K::HW;
+            const int ry = r % K::HP; r /= K::HP;
+            const int cil = r % K::KC; r /= K::KC;
+            const int ti = r;
+            const int yy = y0 - 1 + ry, xx = x0 - 1 + rx;
+            x_dst[i] = ti * K::XI + cil * K::XS + ry * K::XW + rx;
+            x_img[i] = ti * K::KC + cil;                               // (image, channel-in-chunk)
+            if (n0 + ti < p.n && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_)
+                x_src[i] = ((n0 + ti) * p.cin + cil) * (p.h * p.w_) + yy * p.w_ + xx;   // + ci0 * h * w per chunk
+        }
+    }
+    const int hw = p.h * p.w_;
 
     f32x16 acc[K::MTW][K::NTW];
 #pragma unroll
@@ -75,109 +179,249 @@ modconv_kernel(ide3d_modconv_params p, int tiles_x, int tiles_y, int mblocks) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // B-operand base address of this lane inside the halo patch, per N tile.
+    // B-operand base address of this lane per N tile: pixel j -> (ti, py, px)
     int boff[K::NTW];
 #pragma unroll
     for (int j = 0; j < K::NTW; ++j) {
-        const int py = (wn * K::NTW + j) * 2 + (l32 >> 4), px = l32 & 15;
-        boff[j] = py * K::XW + px;
+        const int pix = (wn * K::NTW + j) * 32 + l32;
+        const int ti = pix / (PH * PW), rem = pix % (PH * PW);
+        boff[j] = ti * K::XI + (rem / PW) * K::XW + (rem % PW) + half * K::XS;
     }
+    const int aoff = half * K::BM + wm * K::MTW * 32 + l32;
 
-    for (int ci0 = 0; ci0 < p.cin; ci0 += K::KC) {
-        // ---- stage weights (x styles) : s_w[(tap*KC + cil)][co] ----
-        for (int e = tid; e < K::BM * K::KK; e += 256) {
-            const int co = e / K::KK, r = e - co * K::KK;
-            const int cil = r / K::TAPS, tap = r - cil * K::TAPS;
-            float v = 0.f;
-            if (co0 + co < p.cout && ci0 + cil < p.cin)
-                v = p.w[((int64_t)(co0 + co) * p.cin + ci0 + cil) * K::TAPS + tap] * sty[ci0 + cil];
-            s_w[(tap * K::KC + cil) * K::WP + co] = v;
-        }
-        // ---- stage input halo patch ----
-        for (int e = tid; e < K::KC * K::HP * K::HW; e += 256) {
-            const int cil = e / (K::HP * K::HW), r = e - cil * (K::HP * K::HW);
-            const int ry = r / K::HW, rx = r - ry * K::HW;
-            const int yy = y0 - PAD + ry, xx = x0 - PAD + rx;
-            float v = 0.f;
-            if (ci0 + cil < p.cin && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_)
-                v = xin[((int64_t)(ci0 + cil) * p.h + yy) * p.w_ + xx];
-            s_x[cil * K::XS + ry * K::XW + rx] = v;
-        }
-        __syncthreads();
-        // ---- MFMA over the chunk: k-step = (tap, channel pair), lane half selects the channel ----
+    const int c_begin = split * g.chunks_per_split;
+    const int c_end = min(c_begin + g.chunks_per_split, g.cchunks);
+
+    float4 wreg[K::NW4];
+    float xreg[K::NXE];
+    auto fetch = [&](int c) {
+        const float* ws = wsrc + (int64_t)c * (K::WTAPS * K::KC * K::BM);
 #pragma unroll
-        for (int tap = 0; tap < K::TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
+        for (int i = 0; i < K::NW4; ++i) {
+            const int q = tid + i * 256;                                   // float4 index inside the staged slab
+            if (q < ntaps * (K::KC * K::BM / 4)) {
+                const int t = q / (K::KC * K::BM / 4), rq = q - t * (K::KC * K::BM / 4);
+                wreg[i] = *reinterpret_cast<const float4*>(ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + rq * 4);
+            }
+        }
+        const int ci0 = c * K::KC;
+#pragma unroll
+        for (int i = 0; i < K::NXE; ++i) {
+            float v = 0.f;
+            const int cil = x_img[i] % K::KC;
+            if (x_src[i] >= 0 && ci0 + cil < p.cin) {
+                v = p.x[(int64_t)x_src[i] + (int64_t)ci0 * hw];
+                if (p.styles) v *= p.styles[(n0 + x_img[i] / K::KC) * p.cin + ci0 + cil];
+            }
+            xreg[i] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < K::NW4; ++i) {
+            const int q = tid + i * 256;
+            if (q < ntaps * (K::KC * K::BM / 4)) *reinterpret_cast<float4*>(&s_w[buf][q * 4]) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < K::NXE; ++i)
+            if (x_dst[i] >= 0) s_x[buf][x_dst[i]] = xreg[i];
+    };
+
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        commit(0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) fetch(c + 1);
+        const float* sw = s_w[buf];
+        const float* sx = s_x[buf];
+        auto tap_body = [&](int t, int off) {
 #pragma unroll
             for (int cp = 0; cp < K::KC / 2; ++cp) {
-                const int cil = cp * 2 + half;
                 float a[K::MTW], b[K::NTW];
 #pragma unroll
-                for (int i = 0; i < K::MTW; ++i)
-                    a[i] = s_w[(tap * K::KC + cil) * K::WP + (wm * K::MTW + i) * 32 + l32];
+                for (int i = 0; i < K::MTW; ++i) a[i] = sw[(t * K::KC + cp * 2) * K::BM + aoff + i * 32];
 #pragma unroll
-                for (int j = 0; j < K::NTW; ++j)
-                    b[j] = s_x[cil * K::XS + boff[j] + ky * K::XW + kx];
+                for (int j = 0; j < K::NTW; ++j) b[j] = sx[boff[j] + cp * 2 * K::XS + off];
 #pragma unroll
                 for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
                     for (int j = 0; j < K::NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        };
+        if (MODE == MODE_TCONV3) {
+            for (int t = 0; t < ntaps; ++t) tap_body(t, sel(t_off, t));
+        } else {
+#pragma unroll
+            for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t]);
         }
+        if (c + 1 < c_end) commit(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue ----
-    float* __restrict__ yout = p.y + (int64_t)n * p.cout * p.h * p.w_;
+    const bool raw = (g.split_k > 1);
 #pragma unroll
     for (int j = 0; j < K::NTW; ++j) {
-        const int py = (wn * K::NTW + j) * 2 + (l32 >> 4), px = l32 & 15;
-        const int yy = y0 + py, xx = x0 + px;
-        const bool pix_ok = yy < p.h && xx < p.w_;
-        const float nz = (p.noise && pix_ok) ? p.noise[yy * p.w_ + xx] * p.noise_strength : 0.f;
+        const int pix = (wn * K::NTW + j) * 32 + l32;
+        const int ti = pix / (PH * PW), rem = pix % (PH * PW);
+        const int n = n0 + ti;
+        const int gy = y0 + rem / PW, gx = x0 + rem % PW;              // (class-)grid coordinates
+        const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy;
+        const int ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
+        const bool ok = n < p.n && oy < g.oh && ox < g.ow;
+        if (!ok) continue;
+        const float nz = (!raw && p.noise) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
+        float* dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int co = co0 + (wm * K::MTW + i) * 32 + row;
-                if (!pix_ok || co >= p.cout) continue;
+                const int co = mb * K::BM + (wm * K::MTW + i) * 32 + row;
+                if (co >= p.cout) continue;
                 float v = acc[i][j][r];
-                if (p.dcoefs) v *= p.dcoefs[(int64_t)n * p.cout + co];
-                v += nz;
-                if (p.bias) v += p.bias[co];
-                if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
-                v *= p.gain;
-                if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-                yout[((int64_t)co * p.h + yy) * p.w_ + xx] = v;
+                if (!raw) {
+                    if (p.dcoefs) v *= p.dcoefs[(int64_t)n * p.cout + co];
+                    v += nz;
+                    if (p.bias) v += p.bias[co];
+                    if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
+                    v *= p.gain;
+                    if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                }
+                dst[(((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox] = v;
             }
     }
 }
 
-template <int KS, int BIG>
-static int launch_modconv(const ide3d_modconv_params& p, hipStream_t st) {
-    using K = McCfg<KS, BIG>;
-    const int tiles_x = cdiv(p.w_, K::PW), tiles_y = cdiv(p.h, K::PH), mblocks = cdiv(p.cout, K::BM);
-    const int64_t nblocks = (int64_t)tiles_x * tiles_y * mblocks * p.n;
-    if (nblocks > 0x7fffffff) { set_error("modconv2d: grid too large"); return IDE3D_EINVAL; }
-    hipLaunchKernelGGL((modconv_kernel<KS, BIG>), dim3((unsigned)nblocks), dim3(256), 0, st, p, tiles_x, tiles_y, mblocks);
-    IDE3D_CHECK_LAUNCH("modconv2d");
-    return IDE3D_OK;
+// reduce split-K partials + epilogue
+__global__ void __launch_bounds__(256)
+modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partial, int split_k, int oh, int ow) {
+    const int64_t per = (int64_t)p.n * p.cout * oh * ow;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += stride) {
+        float v = 0.f;
+        for (int s = 0; s < split_k; ++s) v += partial[s * per + i];
+        const int pix = (int)(i % ((int64_t)oh * ow));
+        const int co = (int)((i / ((int64_t)oh * ow)) % p.cout);
+        const int n = (int)(i / ((int64_t)oh * ow * p.cout));
+        if (p.dcoefs) v *= p.dcoefs[(int64_t)n * p.cout + co];
+        if (p.noise) v += p.noise[pix] * p.noise_strength;
+        if (p.bias) v += p.bias[co];
+        if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
+        v *= p.gain;
+        if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+        p.y[i] = v;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct ConvPlan {
+    int mode, big, tile;             // tile: 0 = 1x8x16, 1 = 2x8x8, 2 = 8x4x4
+    int bm, kc, taps, mblocks, cchunks, oh, ow;
+    int64_t packed_floats, partial_floats;
+    ConvGeom g;
+};
+
+static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
+    pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
+    pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128;
+    pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
+    pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
+    pl.oh = (pl.mode == MODE_TCONV3) ? 2 * p.h + 1 : p.h;
+    pl.ow = (pl.mode == MODE_TCONV3) ? 2 * p.w_ + 1 : p.w_;
+    pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm;
+    // class grids
+    int gh[4], gw[4];
+    const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
+    for (int c = 0; c < 4; ++c) {
+        if (pl.mode == MODE_TCONV3) { gh[c] = (c >> 1) ? p.h : p.h + 1; gw[c] = (c & 1) ? p.w_ : p.w_ + 1; }
+        else { gh[c] = p.h; gw[c] = p.w_; }
+    }
+    const int mind = (p.h < p.w_) ? p.h : p.w_;
+    pl.tile = (mind >= 12) ? 0 : (mind >= 6 ? 1 : 2);
+    static const int TIv[3] = {1, 2, 8}, PHv[3] = {8, 8, 4}, PWv[3] = {16, 8, 4};
+    ConvGeom& g = pl.g;
+    g.tile_base[0] = 0;
+    for (int c = 0; c < 4; ++c) {
+        g.tiles_x[c] = cdiv(gw[c], PWv[pl.tile]); g.tiles_y[c] = cdiv(gh[c], PHv[pl.tile]);
+        g.tile_base[c + 1] = g.tile_base[c] + (c < ncls ? g.tiles_x[c] * g.tiles_y[c] : 0);
+    }
+    g.img_groups = cdiv(p.n, TIv[pl.tile]);
+    g.mblocks = pl.mblocks; g.cchunks = pl.cchunks; g.oh = pl.oh; g.ow = pl.ow;
+    const int64_t base_blocks = (int64_t)g.mblocks * g.tile_base[4] * g.img_groups;
+    int split = 1;
+    if (base_blocks < 512 && pl.cchunks >= 8) {
+        split = (int)cdiv64(768, base_blocks);
+        if (split > pl.cchunks / 4) split = pl.cchunks / 4;
+        if (split > 16) split = 16;
+        if (split < 1) split = 1;
+    }
+    g.chunks_per_split = cdiv(pl.cchunks, split);
+    g.split_k = cdiv(pl.cchunks, g.chunks_per_split);
+    pl.partial_floats = (g.split_k > 1) ? (int64_t)g.split_k * p.n * p.cout * pl.oh * pl.ow : 0;
+}
+
+template <int MODE, int BIG>
+static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
+    const ConvGeom& g = pl.g;
+    const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
+    if (pl.tile == 0)      hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    else                   hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
 }
 
 }  // namespace ide3d
+
+static int check_modconv(const ide3d_modconv_params& p) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(p.n > 0 && p.cin > 0 && p.cout > 0 && p.h > 0 && p.w_ > 0, "modconv2d: bad shape");
+    IDE3D_CHECK_ARG(p.k == 1 || p.k == 3, "modconv2d: kernel size must be 1 or 3 (got %d)", p.k);
+    IDE3D_CHECK_ARG(p.mode == 0 || (p.mode == 2 && p.k == 3), "modconv2d: mode must be 0 (conv) or 2 (3x3 transposed, stride 2)");
+    IDE3D_CHECK_ARG((int64_t)p.n * p.cin * p.h * p.w_ < 0x7fffffffLL, "modconv2d: input too large for 32-bit indexing");
+    return IDE3D_OK;
+}
+
+extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode) {
+    using namespace ide3d;
+    ide3d_modconv_params p{};
+    p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w; p.k = k; p.mode = mode;
+    if (check_modconv(p) != IDE3D_OK) return -1;
+    ConvPlan pl; plan_conv(p, pl);
+    return (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float);
+}
 
 extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(pp != nullptr, "modconv2d: null params");
     const ide3d_modconv_params& p = *pp;
-    IDE3D_CHECK_ARG(p.x && p.w && p.styles && p.y, "modconv2d: null tensor pointer");
-    IDE3D_CHECK_ARG(p.n > 0 && p.cin > 0 && p.cout > 0 && p.h > 0 && p.w_ > 0, "modconv2d: bad shape");
-    IDE3D_CHECK_ARG(p.k == 1 || p.k == 3, "modconv2d: kernel size must be 1 or 3 (got %d)", p.k);
+    IDE3D_CHECK_ARG(p.x && p.w && p.y && p.workspace, "modconv2d: null tensor / workspace pointer");
+    int rc = check_modconv(p);
+    if (rc) return rc;
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
+    ConvPlan pl; plan_conv(p, pl);
+    IDE3D_CHECK_ARG(p.workspace_bytes >= (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float),
+                    "modconv2d: workspace too small (need %lld bytes)", (long long)((pl.packed_floats + pl.partial_floats) * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
-    const bool big = p.cout > 96;
-    if (p.k == 3) return big ? launch_modconv<3, 1>(p, st) : launch_modconv<3, 0>(p, st);
-    return big ? launch_modconv<1, 1>(p, st) : launch_modconv<1, 0>(p, st);
+    float* wp = p.workspace;
+    float* partial = p.workspace + pl.packed_floats;
+    if (!p.weights_packed) {
+        hipLaunchKernelGGL(modconv_pack_kernel, dim3(stream_grid(pl.packed_floats, 256)), dim3(256), 0, st,
+                           p.w, p.cout, p.cin, pl.taps, pl.bm, pl.kc, pl.mblocks, pl.cchunks, wp);
+    }
+    if (pl.mode == MODE_CONV3)       { if (pl.big) launch_tiles<MODE_CONV3, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV3, 0>(p, pl, wp, partial, st); }
+    else if (pl.mode == MODE_CONV1)  { if (pl.big) launch_tiles<MODE_CONV1, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV1, 0>(p, pl, wp, partial, st); }
+    else                             { if (pl.big) launch_tiles<MODE_TCONV3, 1>(p, pl, wp, partial, st); else launch_tiles<MODE_TCONV3, 0>(p, pl, wp, partial, st); }
+    if (pl.g.split_k > 1) {
+        const int64_t per = (int64_t)p.n * p.cout * pl.oh * pl.ow;
+        hipLaunchKernelGGL(modconv_epilogue_kernel, dim3(stream_grid(per, 256)), dim3(256), 0, st, p, partial, pl.g.split_k, pl.oh, pl.ow);
+    }
+    IDE3D_CHECK_LAUNCH("modconv2d");
+    return IDE3D_OK;
 }

@@ -65,6 +65,99 @@ triplane_sample_cl_kernel(const float* __restrict__ planes, int64_t sN, int sH, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 fast path: tap set-up once per sample, shared through LDS; 32-bit buffer addressing.
+//
+// In the kernel above the C/4 lanes of a sample each redo the (identical) coordinate -> tap arithmetic and 64-bit
+// address math, which makes it VALU-bound (~350 VALU per 8 samples).  Here a wavefront takes 64 consecutive samples:
+//   phase A  lane = sample: one coalesced 12-byte coordinate load, three taps, results (4 byte-offsets + 4 masked
+//            weights per plane = 24 dwords) parked in LDS, [sample][24] (conflict-free for the phase-B broadcast reads);
+//   phase B  lane = (sample slot, 4-channel slice): 64 / SPW rounds; per round six ds_read_b128 fetch the sample's
+//            taps, twelve buffer_load_dwordx4 (SGPR base + 32-bit offset, no 64-bit VALU address math) fetch the
+//            C*4-byte tap lines, 24 packed FMAs blend them, one 16-byte store writes the output slice.
+// ------------------------------------------------------------------------------------------------
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    const f32x4_t f = __builtin_bit_cast(f32x4_t, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+template <int LPS>
+__global__ void __launch_bounds__(256)
+triplane_sample_cl2_kernel(const float* __restrict__ planes, unsigned sN_bytes, int sH, int sW, unsigned plane_bytes,
+                           int C, int H, int W, const float* __restrict__ coords, unsigned m,
+                           unsigned rows, float* __restrict__ out, unsigned rows_per_block) {
+    constexpr int SPW = kWave / LPS;                     // samples per phase-B round
+    constexpr int ROUNDS = kWave / SPW;                  // = LPS
+    __shared__ __attribute__((aligned(16))) unsigned s_tap[4][kWave][24];
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int slot = lane / LPS, cl = lane % LPS;
+    unsigned (*tap)[24] = s_tap[wid];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)planes, 0, (int)plane_bytes, 0x00020000);
+
+    const unsigned blk = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned row_begin = blk * rows_per_block;
+    unsigned row_end = row_begin + rows_per_block;
+    if (row_end > rows) row_end = rows;
+    const unsigned ch_bytes = (unsigned)cl * 16u;
+
+    for (unsigned base = row_begin + wid * kWave; base < row_end; base += 4 * kWave) {
+        // ---- phase A ----
+        {
+            const unsigned row = min(base + lane, rows - 1);
+            const float* cp = coords + (size_t)row * 3;
+            const float cx = cp[0], cy = cp[1], cz = cp[2];
+            const unsigned img = (row / m) * sN_bytes;
+            const TapAddr t0 = make_tap_addr(cx, cy, W, H, sH, sW);
+            const TapAddr t1 = make_tap_addr(cy, cz, W, H, sH, sW);
+            const TapAddr t2 = make_tap_addr(cx, cz, W, H, sH, sW);
+            const unsigned p1 = img + (unsigned)C * 4u, p2 = img + (unsigned)C * 8u;
+            u32x4* dst = reinterpret_cast<u32x4*>(tap[lane]);
+            dst[0] = u32x4{img + (unsigned)t0.o00 * 4u, img + (unsigned)t0.o01 * 4u, img + (unsigned)t0.o10 * 4u, img + (unsigned)t0.o11 * 4u};
+            dst[1] = u32x4{__float_as_uint(t0.w00), __float_as_uint(t0.w01), __float_as_uint(t0.w10), __float_as_uint(t0.w11)};
+            dst[2] = u32x4{p1 + (unsigned)t1.o00 * 4u, p1 + (unsigned)t1.o01 * 4u, p1 + (unsigned)t1.o10 * 4u, p1 + (unsigned)t1.o11 * 4u};
+            dst[3] = u32x4{__float_as_uint(t1.w00), __float_as_uint(t1.w01), __float_as_uint(t1.w10), __float_as_uint(t1.w11)};
+            dst[4] = u32x4{p2 + (unsigned)t2.o00 * 4u, p2 + (unsigned)t2.o01 * 4u, p2 + (unsigned)t2.o10 * 4u, p2 + (unsigned)t2.o11 * 4u};
+            dst[5] = u32x4{__float_as_uint(t2.w00), __float_as_uint(t2.w01), __float_as_uint(t2.w10), __float_as_uint(t2.w11)};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B ----
+#pragma unroll 2
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int s = r * SPW + slot;
+            const unsigned row = base + s;
+            const u32x4* src = reinterpret_cast<const u32x4*>(tap[s]);
+            float4 acc[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x4 o = src[2 * pl];
+                const u32x4 wq = src[2 * pl + 1];
+                const float4 v00 = buf_ld4(rsrc, o.x + ch_bytes);
+                const float4 v01 = buf_ld4(rsrc, o.y + ch_bytes);
+                const float4 v10 = buf_ld4(rsrc, o.z + ch_bytes);
+                const float4 v11 = buf_ld4(rsrc, o.w + ch_bytes);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                a = f4_fma(v00, __uint_as_float(wq.x), a);
+                a = f4_fma(v01, __uint_as_float(wq.y), a);
+                a = f4_fma(v10, __uint_as_float(wq.z), a);
+                a = f4_fma(v11, __uint_as_float(wq.w), a);
+                acc[pl] = a;
+            }
+            if (row < row_end) {
+                f32x4_t res = {(acc[0].x + acc[1].x) + acc[2].x, (acc[0].y + acc[1].y) + acc[2].y,
+                               (acc[0].z + acc[1].z) + acc[2].z, (acc[0].w + acc[1].w) + acc[2].w};
+                __builtin_nontemporal_store(res, reinterpret_cast<f32x4_t*>(out + (size_t)row * C + cl * 4));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // General strided path (NCHW or anything else): one lane per sample, loop over channels; the
 // output tile of the workgroup is transposed through LDS so that stores stay coalesced.
 __global__ void __launch_bounds__(256)
@@ -187,9 +280,35 @@ triplane_backward_kernel(const float* __restrict__ grad_out, const float* __rest
     }
 }
 
+// v2 launcher: images are processed in groups whose planes span < 2 GiB so that byte offsets fit 32 bits.
+template <int LPS>
+static bool launch_cl2(const float* planes, const int64_t* s, int n, int C, int H, int W,
+                       const float* coords, int64_t m, float* out, hipStream_t st) {
+    const int64_t sN_bytes = s[0] * 4;
+    if (m <= 0 || m >= (1LL << 31) || sN_bytes <= 0 || sN_bytes >= (1LL << 31)) return false;
+    if ((int64_t)H * s[2] * 4 > sN_bytes || s[0] < 0) return false;
+    int group = (int)((((1LL << 31) - 1) / sN_bytes));
+    if (group < 1) return false;
+    while ((int64_t)group * m >= (1LL << 31)) group >>= 1;
+    if (group < 1) return false;
+    for (int n0 = 0; n0 < n; n0 += group) {
+        const int cnt = (n - n0 < group) ? n - n0 : group;
+        const unsigned rows = (unsigned)((int64_t)cnt * m);
+        int64_t nblk = kNumCU * 6;
+        unsigned rpb = (unsigned)(cdiv64(cdiv64(rows, nblk), 256) * 256);
+        if (rpb < 256) rpb = 256;
+        nblk = cdiv64(rows, rpb);
+        hipLaunchKernelGGL((triplane_sample_cl2_kernel<LPS>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           planes + (int64_t)n0 * s[0], (unsigned)sN_bytes, (int)s[2], (int)s[3], (unsigned)(cnt * sN_bytes),
+                           C, H, W, coords + (int64_t)n0 * m * 3, (unsigned)m, rows, out + (int64_t)n0 * m * C, rpb);
+    }
+    return true;
+}
+
 template <int LPS>
 static void launch_cl(const float* planes, const int64_t* s, int n, int C, int H, int W,
                       const float* coords, int64_t m, float* out, hipStream_t st) {
+    if (launch_cl2<LPS>(planes, s, n, C, H, W, coords, m, out, st)) return;
     const int64_t rows = (int64_t)n * m;
     constexpr int SPB = (kWave / LPS) * 4;
     // ~8 workgroups per CU; contiguous chunks, multiple of the per-iteration sample count.

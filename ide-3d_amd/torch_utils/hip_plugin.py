@@ -98,6 +98,8 @@ class _ModconvParams(ctypes.Structure):
         ('h', ctypes.c_int32), ('w_', ctypes.c_int32), ('k', ctypes.c_int32),
         ('noise_strength', ctypes.c_float),
         ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
+        ('mode', ctypes.c_int32), ('weights_packed', ctypes.c_int32),
+        ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
     ]
 
 
@@ -159,11 +161,12 @@ def load():
             'ide3d_render_rays': [ctypes.POINTER(_RenderParams), vp],
             'ide3d_sample_voxel': [ctypes.POINTER(_RenderParams), vp, i64, vp, vp, ctypes.c_int, vp],
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
+            'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
         }
         for name, argtypes in protos.items():
             fn = getattr(lib, name)          # AttributeError here = header / library mismatch
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_int64 if name.endswith('_bytes') else ctypes.c_int
             fn.argtypes = argtypes
         _lib = lib
         return _lib
@@ -173,7 +176,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
-    'ide3d_modconv2d', 'ide3d_frame_u8',
+    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8',
 )
 
 
@@ -537,18 +540,35 @@ class VolumeRenderPlugin:
 
 
 class ModconvPlugin:
+    # workspace cache: (weight data_ptr, shape, n, h, w, mode) -> [buffer, weight._version the packed copy was made from]
+    _ws = {}
+
     @staticmethod
-    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp):
-        for t in (x, w, styles):
+    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0):
+        """mode 0: stride-1 k x k modulated conv with fused epilogue; mode 2: 3x3 transposed stride-2 conv
+        (output (2h+1) x (2w+1), demodulation applied, no noise / bias / activation unless given)."""
+        for t in (x, w):
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'modconv2d: contiguous float32 CUDA tensors required')
         n, cin, h, wd = x.shape
         cout, cin2, k, k2 = w.shape
         _require(cin == cin2 and k == k2 and k in (1, 3), 'modconv2d: weight must be [cout, cin, k, k] with k in {1, 3}')
-        y = torch.empty([n, cout, h, wd], dtype=torch.float32, device=x.device)
+        _require(mode in (0, 2), 'modconv2d: mode must be 0 or 2')
+        oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (h, wd)
+        y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+        lib = load()
+        key = (w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index)
+        ent = ModconvPlugin._ws.get(key)
+        if ent is None:
+            nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode)
+            _require(nbytes >= 0, 'modconv2d: unsupported configuration')
+            if len(ModconvPlugin._ws) > 256:
+                ModconvPlugin._ws.clear()
+            ent = [torch.empty([max(nbytes // 4, 1)], dtype=torch.float32, device=x.device), None]
+            ModconvPlugin._ws[key] = ent
         p = _ModconvParams()
-        p.x, p.w, p.styles, p.y = x.data_ptr(), w.data_ptr(), styles.data_ptr(), y.data_ptr()
+        p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
         keep = []
-        for name, t in (('dcoefs', dcoefs), ('noise', noise), ('bias', bias)):
+        for name, t in (('styles', styles), ('dcoefs', dcoefs), ('noise', noise), ('bias', bias)):
             if t is not None:
                 t = t.contiguous(); keep.append(t)
                 _require(t.is_cuda and t.dtype == torch.float32, f'modconv2d: {name} must be float32 on GPU')
@@ -556,9 +576,13 @@ class ModconvPlugin:
         p.n, p.cin, p.cout, p.h, p.w_, p.k = n, cin, cout, h, wd, k
         p.noise_strength = float(noise_strength)
         p.act, p.alpha, p.gain, p.clamp = int(act), float(alpha), float(gain), float(clamp)
+        p.mode = mode
+        p.weights_packed = int(ent[1] == w._version)
+        p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         with torch.cuda.device(x.device):
-            rc = load().ide3d_modconv2d(ctypes.byref(p), _stream(x))
+            rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
+        ent[1] = w._version
         return y
 
 

@@ -308,6 +308,17 @@ class SynthesisLayer(torch.nn.Module):
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
 
+        if (self.up == 2 and use_hip_modconv and self.weight.shape[2] == 3 and self.padding == 1
+                and _inference_on_gpu(x, self.weight, styles, self.bias) and _modconv_init()):
+            # up-sampling layer, MI355X inference path (same strategy as conv2d_resample.py:112-129): transposed
+            # 3x3 stride-2 conv as a parity-class implicit GEMM (demodulation fused), then the 4x4 FIR with gain 4.
+            dcoefs = _demod_coefs(self.weight, styles)
+            y = _modconv_plugin.modconv2d(x.contiguous(), self.weight.contiguous(), styles.contiguous(), dcoefs,
+                                          None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
+            y = upfirdn2d.upfirdn2d(y, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+            if noise is not None:
+                y = y.add_(noise)
+            return bias_act.bias_act(y, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
         if self.up == 1:
             # single-launch path: conv + const/absent noise + bias + activation
             if noise is None or (const_noise and input_noise is None and noise.shape == x.shape[2:]):

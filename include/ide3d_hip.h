@@ -259,8 +259,15 @@ typedef struct ide3d_modconv_params {
     int32_t n, cin, cout, h, w_, k;
     float noise_strength;
     int32_t act; float alpha, gain, clamp;
+    int32_t mode;             /* 0: stride-1 k x k "same" correlation (y is h x w);
+                                 2: 3x3 transposed convolution, stride 2, pad 0 (y is (2h+1) x (2w+1)) —
+                                    `conv_transpose2d(x, w.transpose(0,1), stride=2)` of conv2d_resample.py:114-125 */
+    int32_t weights_packed;   /* 1: `workspace` already holds the packed form of `w` from an earlier call */
+    float*  workspace;        /* scratch of ide3d_modconv_workspace_bytes(): packed weights, then split-K partials */
+    int64_t workspace_bytes;
 } ide3d_modconv_params;
 
+int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode);
 int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
 
 /* ---- output post-processing -------------------------------------------- */

@@ -333,6 +333,44 @@ def test_modconv2d_against_conv2d(gpu_device, n, cin, cout, h, w, k):
     assert_close(y, ref.float(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), what=f'modconv {n, cin, cout, h, w, k}')
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 8, 16, 4, 4), (1, 20, 150, 9, 13), (4, 512, 512, 8, 8), (2, 64, 32, 33, 20), (3, 12, 130, 5, 7)])
+def test_modconv2d_transposed_against_conv_transpose2d(gpu_device, n, cin, cout, h, w):
+    """mode 2 == conv_transpose2d(x * s, w.transpose(0, 1), stride=2) * d  (conv2d_resample.py:114-125); also covers
+    split-K (512 channels at 8x8) and the 2x8x8 / 8x4x4 pixel tiles."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    s = torch.randn(n, cin, generator=g) + 1
+    d = torch.rand(n, cout, generator=g) + 0.5
+    ref = torch.nn.functional.conv_transpose2d((x * s[:, :, None, None]).double(), wt.transpose(0, 1).double(), stride=2) * d.double()[:, :, None, None]
+    y = hip_plugin.ModconvPlugin.modconv2d(x.to(gpu_device), wt.to(gpu_device), s.to(gpu_device), d.to(gpu_device), None, 0.0, None,
+                                           1, 0.0, 1.0, -1.0, mode=2)
+    assert y.shape == (n, cout, 2 * h + 1, 2 * w + 1)
+    scale = float(ref.abs().max())
+    assert_close(y, ref.float(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), what=f'tconv {n, cin, cout, h, w}')
+    # weights cached in packed form: a second call (weights_packed = 1) gives the same answer
+    y2 = hip_plugin.ModconvPlugin.modconv2d(x.to(gpu_device), wt.to(gpu_device), s.to(gpu_device), d.to(gpu_device), None, 0.0, None,
+                                            1, 0.0, 1.0, -1.0, mode=2)
+    assert torch.equal(y, y2)
+
+
+def test_modconv2d_low_resolution_split_k(gpu_device):
+    """512 -> 512 channels at 4x4 / 8x8 / 16x16 / 32x32, batch 4: split-K path + image-batched pixel tiles."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(15)
+    for res in (4, 8, 16, 32):
+        x = torch.randn(4, 512, res, res, generator=g); wt = torch.randn(512, 512, 3, 3, generator=g) * 0.05
+        s = torch.randn(4, 512, generator=g) + 1; d = torch.rand(4, 512, generator=g) + 0.5
+        nz = torch.randn(res, res, generator=g); b = torch.randn(512, generator=g)
+        ref = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d.double()[:, :, None, None]
+        ref = ref + 0.5 * nz.double() + b.double()[None, :, None, None]
+        ref = torch.where(ref > 0, ref, ref * 0.2) * math.sqrt(2)
+        y = hip_plugin.ModconvPlugin.modconv2d(x.to(gpu_device), wt.to(gpu_device), s.to(gpu_device), d.to(gpu_device), nz.to(gpu_device), 0.5,
+                                               b.to(gpu_device), 3, 0.2, math.sqrt(2), -1.0)
+        assert_close(y, ref.float(), rtol=1e-4, atol=2e-5 * float(ref.abs().max()), what=f'res {res}')
+
+
 def test_modulated_conv2d_surface(golden, gpu_device):
     from training import networks
     from torch_utils.ops import upfirdn2d
