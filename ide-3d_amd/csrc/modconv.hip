@@ -192,44 +192,48 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     const int c_begin = split * g.chunks_per_split;
     const int c_end = min(c_begin + g.chunks_per_split, g.cchunks);
 
+    // Staging is split into an issue-only half (unconditional loads from clamped addresses: no exec-mask
+    // branches, no vmcnt(0) between loads) and a commit half that runs after the MFMAs of the current chunk.
     float4 wreg[K::NW4];
-    float xreg[K::NXE];
+    float xreg[K::NXE], sreg[K::NXE];
+    const int wq_lim = ntaps * (K::KC * K::BM / 4);
+    const int img_last = p.n - 1;
     auto fetch = [&](int c) {
         const float* ws = wsrc + (int64_t)c * (K::WTAPS * K::KC * K::BM);
 #pragma unroll
         for (int i = 0; i < K::NW4; ++i) {
-            const int q = tid + i * 256;                                   // float4 index inside the staged slab
-            if (q < ntaps * (K::KC * K::BM / 4)) {
-                const int t = q / (K::KC * K::BM / 4), rq = q - t * (K::KC * K::BM / 4);
-                wreg[i] = *reinterpret_cast<const float4*>(ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + rq * 4);
-            }
+            const int q = min(tid + i * 256, wq_lim - 1);                  // float4 index inside the staged slab
+            const int t = q / (K::KC * K::BM / 4), rq = q - t * (K::KC * K::BM / 4);
+            wreg[i] = *reinterpret_cast<const float4*>(ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + rq * 4);
         }
         const int ci0 = c * K::KC;
 #pragma unroll
         for (int i = 0; i < K::NXE; ++i) {
-            float v = 0.f;
             const int cil = x_img[i] % K::KC;
-            if (x_src[i] >= 0 && ci0 + cil < p.cin) {
-                v = p.x[(int64_t)x_src[i] + (int64_t)ci0 * hw];
-                if (p.styles) v *= p.styles[(n0 + x_img[i] / K::KC) * p.cin + ci0 + cil];
-            }
-            xreg[i] = v;
+            const int ci = min(ci0 + cil, p.cin - 1);
+            const int64_t src = (x_src[i] >= 0) ? (int64_t)x_src[i] + (int64_t)(ci - cil) * hw : 0;
+            xreg[i] = p.x[src];
+            sreg[i] = p.styles ? p.styles[min(n0 + x_img[i] / K::KC, img_last) * p.cin + ci] : 1.0f;
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int c) {
 #pragma unroll
         for (int i = 0; i < K::NW4; ++i) {
             const int q = tid + i * 256;
-            if (q < ntaps * (K::KC * K::BM / 4)) *reinterpret_cast<float4*>(&s_w[buf][q * 4]) = wreg[i];
+            if (q < wq_lim) *reinterpret_cast<float4*>(&s_w[buf][q * 4]) = wreg[i];
         }
+        const int ci0 = c * K::KC;
 #pragma unroll
-        for (int i = 0; i < K::NXE; ++i)
-            if (x_dst[i] >= 0) s_x[buf][x_dst[i]] = xreg[i];
+        for (int i = 0; i < K::NXE; ++i) {
+            const int cil = x_img[i] % K::KC;
+            const bool live = x_src[i] >= 0 && ci0 + cil < p.cin;
+            if (x_dst[i] >= 0) s_x[buf][x_dst[i]] = live ? xreg[i] * sreg[i] : 0.f;
+        }
     };
 
     if (c_begin < c_end) {
         fetch(c_begin);
-        commit(0);
+        commit(0, c_begin);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
@@ -258,7 +262,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 #pragma unroll
             for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t]);
         }
-        if (c + 1 < c_end) commit(buf ^ 1);
+        if (c + 1 < c_end) commit(buf ^ 1, c + 1);
         __syncthreads();
     }
 
