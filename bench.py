@@ -29,6 +29,7 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK = 157.3e12    # FLOP/s
 BATCH = 4                    # seeds per rank per step (BASELINE config 2)
+PROFILE_ROUND = 'round1'
 
 
 def gather_bytes(n_images, C=32, H=256, W=256, M=64 * 64 * 96, triplanes=1):
@@ -83,8 +84,14 @@ def bench_gather(device, iters=20):
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     avg = sum(ms) / len(ms)
     algo = gather_bytes(n)
-    return dict(kernel='triplane_sample_cl_kernel', bound='hbm', achieved=algo / (avg * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                frac=algo / (avg * 1e-3) / HBM_PEAK, traffic=None, bytes_per_launch=algo, avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
+    # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'gather_pmc.json')
+    if os.path.isfile(pmc):
+        traffic = json.load(open(pmc)).get('hbm_traffic_bytes_per_launch')
+    return dict(kernel='triplane_sample_cl2_kernel', bound='hbm', achieved=algo / (avg * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                frac=algo / (avg * 1e-3) / HBM_PEAK, traffic=traffic, bytes_per_launch=algo, avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 
 
@@ -96,10 +103,19 @@ def cpu_baseline(budget_s=20.0):
     G = triplane.TriPlaneGenerator().eval()
     sd = {k: v.detach() for k, v in G.state_dict().items()}
     sp = ospec.Spec()
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     c = triplane.camera_label(0.0)
     cond = triplane.conditioning_label()
+    # pick the thread count that is fastest on this host (a 256-thread pool is slower than 32 on small conv shapes)
+    probe_ws = ogen.mapping(sd, sp, torch.zeros(1, 512), cond, ops=fast_ops)
+    probe_feat = torch.randn(1, sp.feature_channels + sp.seg_channels, 64, 64)
+    best, cores = None, 1
+    for t in sorted({min(os.cpu_count() or 1, n) for n in (8, 16, 32, 64, 128, 256)}):
+        torch.set_num_threads(t)
+        ogen.superres(sd, sp, probe_feat, probe_ws, 'const', fast_ops)
+        t0 = time.perf_counter(); ogen.superres(sd, sp, probe_feat, probe_ws, 'const', fast_ops); dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, t
+    torch.set_num_threads(cores)
 
     def one(seed):
         z = torch.from_numpy(np.random.RandomState(seed).randn(1, 512))
@@ -115,7 +131,7 @@ def cpu_baseline(budget_s=20.0):
         if dt > budget_s or n >= 8:
             break
     return dict(value=n / dt, unit='frames/s', cores=cores, kind='port',
-                sample=f'{n} full-size 512x512 RGB+seg frames (1 seed each, 96 samples, fp32 torch-CPU oracle), {dt:.1f} s')
+                sample=f'{n} full-size 512x512 RGB+seg frames (1 seed each, 96 samples, fp32 torch-CPU oracle, {cores} of {os.cpu_count()} host threads), {dt:.1f} s')
 
 
 def main():
@@ -143,6 +159,7 @@ def main():
 
     from torch_utils import hip_plugin
     from training import triplane
+    from training import distributed_render as dr
     hip_plugin.load()     # hard error if the HIP library is missing
 
     torch.manual_seed(0)  # same random-init weights on every rank
@@ -151,9 +168,7 @@ def main():
     cond = triplane.conditioning_label(device).repeat(BATCH, 1)
     yaws = [-0.5, 0.0, 0.5, 0.25]
     cams = torch.cat([triplane.camera_label(y, device=device) for y in yaws])
-    palette = torch.tensor([[0, 0, 0], [204, 0, 0], [76, 153, 0], [204, 204, 0], [51, 51, 255], [204, 0, 204], [0, 255, 255],
-                            [255, 204, 204], [102, 51, 0], [255, 0, 0], [102, 204, 0], [255, 255, 0], [0, 0, 153], [0, 0, 204],
-                            [255, 51, 153], [0, 204, 204], [0, 51, 0], [255, 153, 51], [0, 204, 0]], dtype=torch.uint8, device=device)
+    palette = dr.palette_tensor(spec.seg_channels, device)
     gathered = [torch.empty([BATCH, 512, 1024, 3], dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
 
     def step(i):
@@ -162,7 +177,7 @@ def main():
         with torch.no_grad():
             ws = G.mapping(z, cond)
             img, seg = G.synthesis(ws, c=cams, noise_mode='const', return_seg=True)
-            frames = hip_plugin.FramePlugin.frame_u8(img, seg, palette)
+            frames = dr.frames_u8(img, seg, palette)
         if dist:
             dist.gather(frames, gathered, dst=0)
         return frames

@@ -1,0 +1,132 @@
+"""Batched multi-seed / multi-camera rendering sharded over the GPUs of one node.
+
+The reference renders strictly one image per `G.synthesis` call on one GPU (gen_images.py:88-114,
+gen_videos.py:114-139).  Every (seed, camera) pair is independent, so the MI355X build shards the work list
+one rank per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI) with NO collective on the data path;
+the only exchange is the final gather of finished uint8 frames to rank 0 (config 4 of BASELINE.json: 64 seeds x 8
+poses -> grid video).  Frames travel as uint8 RGB | coloured-segmentation (6 bytes / pixel) instead of fp32 image +
+19-channel logits (88 bytes / pixel): the argmax + palette look-up of `mask2color` (dnnlib/seg_tools.py:75-81) and the
+uint8 conversion of `layout_grid` (dnnlib/util.py:637) run on the producing GPU (`csrc/frame.hip`).
+
+Work assignment keeps all poses of a seed on one rank (the mapping network and — with `cache_backbone` — the
+pose-independent tri-planes are evaluated once per seed).
+"""
+
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from torch_utils import custom_ops
+from training import triplane
+
+# 19-class face-parsing palette (dnnlib/seg_tools.py:13-32)
+PALETTE = ((0, 0, 0), (204, 0, 0), (76, 153, 0), (204, 204, 0), (51, 51, 255), (204, 0, 204), (0, 255, 255), (255, 204, 204),
+           (102, 51, 0), (255, 0, 0), (102, 204, 0), (255, 255, 0), (0, 0, 153), (0, 0, 204), (255, 51, 153), (0, 204, 204),
+           (0, 51, 0), (255, 153, 51), (0, 204, 0))
+
+_frame_plugin = None
+
+
+def palette_tensor(num_classes, device):
+    pal = [PALETTE[i % len(PALETTE)] for i in range(num_classes)]
+    return torch.tensor(pal, dtype=torch.uint8, device=device)
+
+
+def frames_u8(img, seg, palette=None):
+    """[N, 3, H, W] image in [-1, 1] + [N, K, H, W] logits -> uint8 [N, H, 2W, 3] (RGB | palette[argmax seg])."""
+    global _frame_plugin
+    if palette is None:
+        palette = palette_tensor(seg.shape[1], img.device)
+    if img.device.type == 'cuda' and img.dtype == torch.float32 and img.shape[-1] % 4 == 0:
+        if _frame_plugin is None:
+            _frame_plugin = custom_ops.get_plugin(module_name='frame_plugin', sources=['frame.hip'])
+        return _frame_plugin.frame_u8(img, seg.float(), palette)
+    rgb = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    col = palette[torch.argmax(seg, dim=1)]
+    return torch.cat([rgb, col], dim=2).contiguous()
+
+
+def shard_items(num_seeds: int, num_poses: int, rank: int, world: int) -> List[Tuple[int, int]]:
+    """(seed index, pose index) pairs of this rank: seeds are dealt round-robin, every pose of a seed stays together."""
+    return [(s, p) for s in range(rank, num_seeds, world) for p in range(num_poses)]
+
+
+def item_index(seed_idx: int, pose_idx: int, num_poses: int) -> int:
+    return seed_idx * num_poses + pose_idx
+
+
+@torch.no_grad()
+def render_items(G, seeds: Sequence[int], yaws: Sequence[float], items: Sequence[Tuple[int, int]], device, batch: int = 4,
+                 truncation_psi: float = 1.0, noise_mode: str = 'const', cache_backbone: bool = True, jitter_seed=None):
+    """Render the given (seed, pose) pairs; returns uint8 frames [len(items), H, 2W, 3] in item order."""
+    if len(items) == 0:
+        res = G.img_resolution
+        return torch.empty([0, res, 2 * res, 3], dtype=torch.uint8, device=device)
+    cond = triplane.conditioning_label(device)
+    cams = {p: triplane.camera_label(yaws[p], device=device) for p in sorted({p for _, p in items})}
+    palette = palette_tensor(G.synthesis.seg_channels, device)
+    ws_cache, plane_cache, out = {}, {}, []
+    for start in range(0, len(items), batch):
+        chunk = items[start:start + batch]
+        for s, _ in chunk:
+            if s not in ws_cache:
+                z = torch.from_numpy(np.random.RandomState(seeds[s]).randn(1, G.z_dim)).to(device)
+                ws_cache[s] = G.mapping(z, cond, truncation_psi=truncation_psi)
+                if cache_backbone:
+                    voxel_ws, _ = G.synthesis.split_ws(ws_cache[s])
+                    plane_cache[s] = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode, force_fp32=True)
+        ws = torch.cat([ws_cache[s] for s, _ in chunk])
+        c = torch.cat([cams[p] for _, p in chunk])
+        planes = None
+        if cache_backbone:
+            planes = (torch.cat([plane_cache[s][0] for s, _ in chunk]), torch.cat([plane_cache[s][1] for s, _ in chunk]))
+        jit = None
+        if jitter_seed is not None:      # reproducible stratified jitter (same draws whatever the sharding)
+            g = G.synthesis
+            jit = torch.stack([torch.rand([g.render_size ** 2, g.spec.num_steps],
+                                          generator=torch.Generator().manual_seed(jitter_seed + item_index(s, p, len(yaws)))) for s, p in chunk]).to(device)
+        img, seg = G.synthesis(ws, c=c, noise_mode=noise_mode, return_seg=True, cached_planes=planes, ray_jitter=jit)
+        out.append(frames_u8(img, seg, palette))
+        # drop cached tri-planes of seeds that are finished
+        done = {s for s, _ in items[:start + batch]} - {s for s, _ in items[start + batch:]}
+        for s in done:
+            plane_cache.pop(s, None)
+    return torch.cat(out)
+
+
+def gather_frames(frames: torch.Tensor, counts: Sequence[int], rank: int, world: int, dst: int = 0):
+    """Gather per-rank uint8 frame stacks (different lengths allowed) on `dst`; returns the list of per-rank tensors
+    on `dst`, None elsewhere.  One direct peer->root transfer per rank (xGMI is fully connected)."""
+    import torch.distributed as dist
+    if world == 1:
+        return [frames]
+    cap = max(counts)
+    pad = frames
+    if frames.shape[0] < cap:
+        pad = torch.cat([frames, frames.new_zeros([cap - frames.shape[0], *frames.shape[1:]])])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:counts[r]] for r, b in enumerate(bufs)]
+
+
+@torch.no_grad()
+def render_grid_sharded(G, seeds: Sequence[int], yaws: Sequence[float], device, rank: int = 0, world: int = 1, batch: int = 4,
+                        **render_kwargs):
+    """Config 4: every rank renders its shard, rank 0 receives all frames ordered as [seed][pose].
+    Returns uint8 [len(seeds) * len(yaws), H, 2W, 3] on rank 0, None on other ranks."""
+    items = shard_items(len(seeds), len(yaws), rank, world)
+    frames = render_items(G, seeds, yaws, items, device, batch=batch, **render_kwargs)
+    counts = [len(shard_items(len(seeds), len(yaws), r, world)) for r in range(world)]
+    parts = gather_frames(frames, counts, rank, world)
+    if parts is None:
+        return None
+    res = frames.new_empty([len(seeds) * len(yaws), *frames.shape[1:]])
+    for r, part in enumerate(parts):
+        idx = [item_index(s, p, len(yaws)) for s, p in shard_items(len(seeds), len(yaws), r, world)]
+        if idx:
+            res[torch.tensor(idx, device=res.device)] = part.to(res.device)
+    return res
