@@ -49,8 +49,9 @@ struct McCfg {
     static constexpr int MTW = BIG ? 2 : 1;                 // 32-row M tiles per wave
     static constexpr int NTW = 4 / WN;                      // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
-    static constexpr int HP = PH + 2, HW = PW + 2;          // halo patch
-    static constexpr int XW = HW + 2;                       // LDS row pitch
+    static constexpr int HALO = (MODE == MODE_CONV1) ? 0 : 1;
+    static constexpr int HP = PH + 2 * HALO, HW = PW + 2 * HALO;   // (halo) patch
+    static constexpr int XW = (MODE == MODE_CONV1) ? PW : HW + 2;  // LDS row pitch
     static constexpr int XS = HP * XW;                      // per-channel pitch
     static constexpr int XI = KC * XS;                      // per-image pitch
     static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
@@ -74,9 +75,9 @@ __host__ __device__ inline int mc_kc(int k) { return k == 3 ? 4 : 16; }
 // weight packing: w [cout, cin, k, k] -> [mb][cc][tap][cil][co]  (zero padded to full blocks)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-modconv_pack_kernel(const float* __restrict__ w, int cout, int cin, int taps, int bm, int kc, int mblocks, int cchunks,
-                    float* __restrict__ out) {
-    const int64_t total = (int64_t)mblocks * cchunks * taps * kc * bm;
+modconv_pack_kernel(const float* __restrict__ w, int64_t w_batch_stride, int nbatch, int cout, int cin, int taps, int bm, int kc,
+                    int mblocks, int cchunks, float* __restrict__ out) {
+    const int64_t total = (int64_t)nbatch * mblocks * cchunks * taps * kc * bm;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int64_t r = i;
@@ -84,9 +85,10 @@ modconv_pack_kernel(const float* __restrict__ w, int cout, int cin, int taps, in
         const int cil = (int)(r % kc); r /= kc;
         const int tap = (int)(r % taps); r /= taps;
         const int cc = (int)(r % cchunks); r /= cchunks;
-        const int mb = (int)r;
+        const int mb = (int)(r % mblocks); r /= mblocks;
+        const int nb = (int)r;
         const int co = mb * bm + co_l, ci = cc * kc + cil;
-        out[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * taps + tap] : 0.f;
+        out[i] = (co < cout && ci < cin) ? w[nb * w_batch_stride + ((int64_t)co * cin + ci) * taps + tap] : 0.f;
     }
 }
 
@@ -134,7 +136,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 #pragma unroll
         for (int t = 0; t < 9; ++t) { t_widx[t] = t; t_off[t] = (t / 3) * K::XW + (t % 3); }
     } else if (MODE == MODE_CONV1) {
-        ntaps = 1; t_widx[0] = 0; t_off[0] = K::XW + 1;
+        ntaps = 1; t_widx[0] = 0; t_off[0] = 0;
     } else {
         // out[2i+ky] += x[i] w[ky]:  even output rows take ky = 0 (i = c) and ky = 2 (i = c-1); odd rows ky = 1 (i = c).
         // patch row of input i for grid row c (patch origin = y0 - 1): (c - y0) + 1 + (i - c).
@@ -150,7 +152,8 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     }
 
     // ---- staging plan (fixed across chunks) ----
-    const float* __restrict__ wsrc = wp + (int64_t)mb * g.cchunks * (K::WTAPS * K::KC * K::BM);
+    const float* __restrict__ wsrc = wp + (int64_t)mb * g.cchunks * (K::WTAPS * K::KC * K::BM)
+                                     + (p.w_batch_stride ? (int64_t)n0 * g.mblocks * g.cchunks * (K::WTAPS * K::KC * K::BM) : 0);
     int x_src[K::NXE], x_dst[K::NXE], x_img[K::NXE];
 #pragma unroll
     for (int i = 0; i < K::NXE; ++i) {
@@ -162,7 +165,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
             const int ry = r % K::HP; r /= K::HP;
             const int cil = r % K::KC; r /= K::KC;
             const int ti = r;
-            const int yy = y0 - 1 + ry, xx = x0 - 1 + rx;
+            const int yy = y0 - K::HALO + ry, xx = x0 - K::HALO + rx;
             x_dst[i] = ti * K::XI + cil * K::XS + ry * K::XW + rx;
             x_img[i] = ti * K::KC + cil;                               // (image, channel-in-chunk)
             if (n0 + ti < p.n && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_)
@@ -340,7 +343,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
     pl.oh = (pl.mode == MODE_TCONV3) ? 2 * p.h + 1 : p.h;
     pl.ow = (pl.mode == MODE_TCONV3) ? 2 * p.w_ + 1 : p.w_;
-    pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm;
+    pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -349,7 +352,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         else { gh[c] = p.h; gw[c] = p.w_; }
     }
     const int mind = (p.h < p.w_) ? p.h : p.w_;
-    pl.tile = (mind >= 12) ? 0 : (mind >= 6 ? 1 : 2);
+    pl.tile = (mind >= 12 || p.w_batch_stride) ? 0 : (mind >= 6 ? 1 : 2);     // per-image weights need one image per tile
     static const int TIv[3] = {1, 2, 8}, PHv[3] = {8, 8, 4}, PWv[3] = {16, 8, 4};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
@@ -392,10 +395,11 @@ static int check_modconv(const ide3d_modconv_params& p) {
     return IDE3D_OK;
 }
 
-extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode) {
+extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,
+                                                 int32_t per_image_weights) {
     using namespace ide3d;
     ide3d_modconv_params p{};
-    p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w; p.k = k; p.mode = mode;
+    p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w; p.k = k; p.mode = mode; p.w_batch_stride = per_image_weights ? 1 : 0;
     if (check_modconv(p) != IDE3D_OK) return -1;
     ConvPlan pl; plan_conv(p, pl);
     return (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float);
@@ -417,7 +421,7 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     float* partial = p.workspace + pl.packed_floats;
     if (!p.weights_packed) {
         hipLaunchKernelGGL(modconv_pack_kernel, dim3(stream_grid(pl.packed_floats, 256)), dim3(256), 0, st,
-                           p.w, p.cout, p.cin, pl.taps, pl.bm, pl.kc, pl.mblocks, pl.cchunks, wp);
+                           p.w, p.w_batch_stride, p.w_batch_stride ? p.n : 1, p.cout, p.cin, pl.taps, pl.bm, pl.kc, pl.mblocks, pl.cchunks, wp);
     }
     if (pl.mode == MODE_CONV3)       { if (pl.big) launch_tiles<MODE_CONV3, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV3, 0>(p, pl, wp, partial, st); }
     else if (pl.mode == MODE_CONV1)  { if (pl.big) launch_tiles<MODE_CONV1, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV1, 0>(p, pl, wp, partial, st); }

@@ -100,6 +100,7 @@ class _ModconvParams(ctypes.Structure):
         ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
         ('mode', ctypes.c_int32), ('weights_packed', ctypes.c_int32),
         ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
+        ('w_batch_stride', ctypes.c_int64),
     ]
 
 
@@ -161,7 +162,7 @@ def load():
             'ide3d_render_rays': [ctypes.POINTER(_RenderParams), vp],
             'ide3d_sample_voxel': [ctypes.POINTER(_RenderParams), vp, i64, vp, vp, ctypes.c_int, vp],
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
-            'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32],
+            'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32, i32],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
         }
         for name, argtypes in protos.items():
@@ -550,16 +551,20 @@ class ModconvPlugin:
         for t in (x, w):
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'modconv2d: contiguous float32 CUDA tensors required')
         n, cin, h, wd = x.shape
-        cout, cin2, k, k2 = w.shape
+        per_image = (w.ndim == 5)             # [n, cout, cin, k, k]: styles already folded into per-image weights
+        if per_image:
+            _require(w.shape[0] == n and styles is None, 'modconv2d: per-image weights need w.shape[0] == batch and styles=None')
+        cout, cin2, k, k2 = w.shape[-4:]
         _require(cin == cin2 and k == k2 and k in (1, 3), 'modconv2d: weight must be [cout, cin, k, k] with k in {1, 3}')
         _require(mode in (0, 2), 'modconv2d: mode must be 0 or 2')
+        _require(per_image or styles is not None, 'modconv2d: styles required')
         oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (h, wd)
         y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
         lib = load()
-        key = (w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index)
+        key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index)
         ent = ModconvPlugin._ws.get(key)
         if ent is None:
-            nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode)
+            nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode, int(per_image))
             _require(nbytes >= 0, 'modconv2d: unsupported configuration')
             if len(ModconvPlugin._ws) > 256:
                 ModconvPlugin._ws.clear()
@@ -577,12 +582,13 @@ class ModconvPlugin:
         p.noise_strength = float(noise_strength)
         p.act, p.alpha, p.gain, p.clamp = int(act), float(alpha), float(gain), float(clamp)
         p.mode = mode
-        p.weights_packed = int(ent[1] == w._version)
+        p.weights_packed = int((not per_image) and ent[1] == w._version)
+        p.w_batch_stride = (cout * cin * k * k) if per_image else 0
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         with torch.cuda.device(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
-        ent[1] = w._version
+        ent[1] = None if per_image else w._version
         return y
 
 

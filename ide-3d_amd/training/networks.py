@@ -139,6 +139,29 @@ def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bi
         spec.cuda_idx, spec.def_alpha, gain, -1.0 if clamp is None else clamp)
 
 
+def _dual_head(x, torgb, toseg, w):
+    """toRGB + toSeg of a dual-path block (reference networks.py:1109,1130) as ONE 1x1 implicit-GEMM launch.
+    The two heads modulate with different styles, so the styles are folded into per-image weights
+    [N, Cout_rgb + Cout_seg, Cin, 1, 1] (tiny) and the activation tensor x is read from HBM once.
+    Inference on device tensors only; returns None otherwise."""
+    if not (use_hip_modconv and torgb.weight.shape[2] == 1 and torgb.conv_clamp == toseg.conv_clamp
+            and _inference_on_gpu(x, w, torgb.weight, toseg.weight) and _modconv_init()):
+        return None
+    n = x.shape[0]
+    s_rgb = torgb.affine(w) * torgb.weight_gain
+    s_seg = toseg.affine(w) * toseg.weight_gain
+    if s_rgb.shape[0] != n:
+        return None
+    wr = torgb.weight[None, :, :, 0, 0] * s_rgb[:, None, :]           # [N, Co_rgb, Cin]
+    ws = toseg.weight[None, :, :, 0, 0] * s_seg[:, None, :]
+    wcat = torch.cat([wr, ws], dim=1)[:, :, :, None, None].contiguous()
+    bias = torch.cat([torgb.bias, toseg.bias]).to(x.dtype)
+    clamp = -1.0 if torgb.conv_clamp is None else torgb.conv_clamp
+    y = _modconv_plugin.modconv2d(x.contiguous(), wcat, None, None, None, 0.0, bias, 1, 0.0, 1.0, clamp)
+    co = torgb.weight.shape[0]
+    return y[:, :co], y[:, co:]
+
+
 @persistence.persistent_class
 class FullyConnectedLayer(torch.nn.Module):
     """Equalised-learning-rate dense layer (reference networks.py:136-165)."""
@@ -438,9 +461,13 @@ class SegSynthesisBlock(torch.nn.Module):
             if disable_rgb:
                 img = seg = None
             else:
-                y = self.torgb(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                heads = _dual_head(x, self.torgb, self.toseg, w_shared)
+                if heads is not None:
+                    y, y_seg = heads              # one launch: x is read once for both heads
+                else:
+                    y = self.torgb(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                    y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
                 img = img.add_(y) if img is not None else y
-                y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
                 seg = seg.add_(y_seg) if seg is not None else y_seg
         assert x.dtype == dtype
         assert img is None or img.dtype == torch.float32

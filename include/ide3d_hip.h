@@ -265,9 +265,13 @@ typedef struct ide3d_modconv_params {
     int32_t weights_packed;   /* 1: `workspace` already holds the packed form of `w` from an earlier call */
     float*  workspace;        /* scratch of ide3d_modconv_workspace_bytes(): packed weights, then split-K partials */
     int64_t workspace_bytes;
+    int64_t w_batch_stride;   /* 0: one weight tensor for the batch (modulation via `styles` on the input);
+                                 > 0: per-image weights w + n * w_batch_stride (styles already folded in by the caller:
+                                 lets heads with different styles — toRGB + toSeg, networks.py:1109,1130 — share one launch) */
 } ide3d_modconv_params;
 
-int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode);
+int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,
+                                      int32_t per_image_weights);
 int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
 
 /* ---- output post-processing -------------------------------------------- */
