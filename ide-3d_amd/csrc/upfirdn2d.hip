@@ -20,13 +20,29 @@
 
 namespace ide3d {
 
+// Optional fused epilogue (ide3d_upfirdn2d_ex): FIR -> + add -> + noise -> bias_act.  All-null = plain upfirdn2d.
+template <class T>
+__device__ __forceinline__ typename Elem<T>::math_t
+apply_epilogue(typename Elem<T>::math_t v, const ide3d_upfirdn2d_epilogue& ep, int n, int c, int oy, int ox, int out_w) {
+    using M = typename Elem<T>::math_t;
+    if (ep.add) v += Elem<T>::ld((const T*)ep.add + n * ep.add_stride[0] + c * ep.add_stride[1] + oy * ep.add_stride[2] + ox * ep.add_stride[3]);
+    if (ep.noise) v += (M)(ep.noise[oy * out_w + ox] * ep.noise_strength);
+    if (ep.fused_act) {
+        if (ep.bias) v += Elem<T>::ld((const T*)ep.bias + c);
+        if (ep.act == 3) v = (v > 0) ? v : v * (M)ep.alpha;
+        v *= (M)ep.act_gain;
+        if (ep.clamp >= 0.f) v = (v > (M)ep.clamp) ? (M)ep.clamp : ((v < -(M)ep.clamp) ? -(M)ep.clamp : v);
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic kernel
 // ------------------------------------------------------------------------------------------------
 
 template <class T>
 __global__ void __launch_bounds__(256)
-upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, int c_fastest) {
+upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int c_fastest) {
     using M = typename Elem<T>::math_t;
     const T* __restrict__ x = (const T*)p.x;
     T* __restrict__ y = (T*)p.y;
@@ -66,7 +82,7 @@ upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, int c_fastest) {
             }
         }
         Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3],
-                    acc * (M)p.gain);
+                    apply_epilogue<T>(acc * (M)p.gain, ep, n, c, oy, ox, p.out_w));
     }
 }
 
@@ -91,7 +107,7 @@ struct Axis {
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>
 __global__ void __launch_bounds__(256)
-upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, int tiles_x, int tiles_y) {
+upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int tiles_x, int tiles_y) {
     using M = typename Elem<T>::math_t;
     using AX = Axis<UX, DX, FW>;
     using AY = Axis<UY, DY, FH>;
@@ -182,6 +198,11 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, int tiles_x, int tiles_y) {
             const int ox0 = (UX > 1) ? qx * UX + p.pad_x0 : qx;
             T* yr = yp + oy * p.y_stride[2];
             constexpr int NO = CX * UX;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int ox = ox0 + j;
+                if (ox >= 0 && ox < p.out_w) row[j] = apply_epilogue<T>(row[j], ep, n, c, oy, ox, p.out_w);
+            }
             if constexpr (sizeof(T) == 4 && NO == 4) {
                 if (ox0 >= 0 && ox0 + NO <= p.out_w && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
                     float4 v4 = make_float4(row[0], row[1], row[2], row[3]);
@@ -198,7 +219,7 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, int tiles_x, int tiles_y) {
 }
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>
-static int launch_tile(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+static int launch_tile(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
     constexpr int TCX = 32 * CX, TCY = 8 * CY;
     // Number of cells needed to cover the outputs on each axis.
     auto cells = [](int out, int pad0, int U) {
@@ -212,55 +233,66 @@ static int launch_tile(const ide3d_upfirdn2d_params& p, hipStream_t st) {
     const int64_t nblocks = (int64_t)tiles_x * tiles_y * p.n * p.c;
     if (nblocks > 0x7fffffff) { set_error("upfirdn2d: grid too large"); return IDE3D_EINVAL; }
     hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, CX, CY>), dim3((unsigned)nblocks),
-                       dim3(256), 0, st, p, tiles_x, tiles_y);
+                       dim3(256), 0, st, p, ep, tiles_x, tiles_y);
     IDE3D_CHECK_LAUNCH("upfirdn2d_tile");
     return IDE3D_OK;
 }
 
 template <class T>
-static int launch_generic(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+static int launch_generic(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
     const int64_t total = (int64_t)p.n * p.c * p.out_h * p.out_w;
     const int c_fastest = (p.y_stride[1] == 1 && p.c > 1) ? 1 : 0;
-    hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3(stream_grid(total, 256)), dim3(256), 0, st, p, c_fastest);
+    hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3(stream_grid(total, 256)), dim3(256), 0, st, p, ep, c_fastest);
     IDE3D_CHECK_LAUNCH("upfirdn2d_generic");
     return IDE3D_OK;
 }
 
 template <class T>
-static int dispatch(const ide3d_upfirdn2d_params& p, hipStream_t st) {
+static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
     const bool w_contig = (p.x_stride[3] == 1 && p.y_stride[3] == 1);
     if constexpr (!std::is_same<T, double>::value) {
         if (w_contig && p.f_w == 4 && p.f_h == 4) {
             if (p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1)
-                return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 2>(p, st);
+                return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 2>(p, ep, st);
             if (p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1)
-                return launch_tile<T, 2, 2, 1, 1, 4, 4, 2, 2>(p, st);
+                return launch_tile<T, 2, 2, 1, 1, 4, 4, 2, 2>(p, ep, st);
             if (p.up_x == 1 && p.up_y == 1 && p.down_x == 2 && p.down_y == 2)
-                return launch_tile<T, 1, 1, 2, 2, 4, 4, 4, 2>(p, st);
+                return launch_tile<T, 1, 1, 2, 2, 4, 4, 4, 2>(p, ep, st);
         }
     }
-    return launch_generic<T>(p, st);
+    return launch_generic<T>(p, ep, st);
 }
 
 }  // namespace ide3d
 
-extern "C" int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* pp, void* stream) {
+static int upfirdn2d_entry(const ide3d_upfirdn2d_params* pp, const ide3d_upfirdn2d_epilogue* epp, void* stream) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(pp != nullptr, "upfirdn2d: null params");
     const ide3d_upfirdn2d_params& p = *pp;
+    ide3d_upfirdn2d_epilogue ep{};
+    if (epp) ep = *epp;
     IDE3D_CHECK_ARG(p.x && p.f && p.y, "upfirdn2d: null tensor pointer");
     IDE3D_CHECK_ARG(p.n > 0 && p.c > 0 && p.in_h > 0 && p.in_w > 0, "upfirdn2d: x is empty");
     IDE3D_CHECK_ARG(p.f_h >= 1 && p.f_w >= 1, "upfirdn2d: f is empty");
     IDE3D_CHECK_ARG(p.up_x >= 1 && p.up_y >= 1, "upfirdn2d: upsampling factor must be at least 1");
     IDE3D_CHECK_ARG(p.down_x >= 1 && p.down_y >= 1, "upfirdn2d: downsampling factor must be at least 1");
     IDE3D_CHECK_ARG(p.out_h >= 1 && p.out_w >= 1, "upfirdn2d: output must be at least 1x1");
+    IDE3D_CHECK_ARG(!ep.fused_act || ep.act == 1 || ep.act == 3, "upfirdn2d_ex: fused activation must be linear (1) or lrelu (3)");
     hipStream_t st = (hipStream_t)stream;
     switch (p.dtype) {
-    case IDE3D_F32:  return dispatch<float>(p, st);
-    case IDE3D_F16:  return dispatch<__half>(p, st);
-    case IDE3D_BF16: return dispatch<__hip_bfloat16>(p, st);
-    case IDE3D_F64:  return dispatch<double>(p, st);
+    case IDE3D_F32:  return dispatch<float>(p, ep, st);
+    case IDE3D_F16:  return dispatch<__half>(p, ep, st);
+    case IDE3D_BF16: return dispatch<__hip_bfloat16>(p, ep, st);
+    case IDE3D_F64:  return dispatch<double>(p, ep, st);
     }
     set_error("upfirdn2d: unsupported dtype code %d", p.dtype);
     return IDE3D_EINVAL;
+}
+
+extern "C" int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* pp, void* stream) {
+    return upfirdn2d_entry(pp, nullptr, stream);
+}
+
+extern "C" int ide3d_upfirdn2d_ex(const ide3d_upfirdn2d_params* pp, const ide3d_upfirdn2d_epilogue* ep, void* stream) {
+    return upfirdn2d_entry(pp, ep, stream);
 }

@@ -53,6 +53,16 @@ class _UpfirdnParams(ctypes.Structure):
     ]
 
 
+class _UpfirdnEpilogue(ctypes.Structure):
+    _fields_ = [
+        ('add', ctypes.c_void_p), ('add_stride', ctypes.c_int64 * 4),
+        ('noise', ctypes.c_void_p), ('noise_strength', ctypes.c_float),
+        ('bias', ctypes.c_void_p),
+        ('fused_act', ctypes.c_int32), ('act', ctypes.c_int32),
+        ('alpha', ctypes.c_float), ('act_gain', ctypes.c_float), ('clamp', ctypes.c_float),
+    ]
+
+
 class _FlreluParams(ctypes.Structure):
     _fields_ = [
         ('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('b', ctypes.c_void_p), ('s', ctypes.c_void_p),
@@ -150,6 +160,7 @@ def load():
         protos = {
             'ide3d_bias_act': [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32, f32, f32, i64, i64, i64, vp],
             'ide3d_upfirdn2d': [ctypes.POINTER(_UpfirdnParams), vp],
+            'ide3d_upfirdn2d_ex': [ctypes.POINTER(_UpfirdnParams), ctypes.POINTER(_UpfirdnEpilogue), vp],
             'ide3d_filtered_lrelu': [ctypes.POINTER(_FlreluParams), vp],
             'ide3d_filtered_lrelu_act': [vp, vp, ctypes.c_int, i32, i32, i32, i32, ctypes.POINTER(i64 * 4),
                                          i32, i32, i32, i32, f32, f32, f32, ctypes.c_int, vp],
@@ -174,7 +185,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = (
-    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d',
+    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8',
@@ -255,6 +266,13 @@ class Upfirdn2dPlugin:
 
     @staticmethod
     def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+        return Upfirdn2dPlugin.upfirdn2d_ex(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+
+    @staticmethod
+    def upfirdn2d_ex(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain,
+                     add=None, noise=None, noise_strength=1.0, bias=None, act=None, alpha=0.0, act_gain=1.0, clamp=-1.0):
+        """upfirdn2d with the optional fused epilogue  y = bias_act(FIR(x) + add + noise * noise_strength)
+        (`act` None = no bias/activation stage; 1 linear, 3 lrelu)."""
         _require(x.is_cuda, 'x must reside on CUDA device')
         _require(f.device == x.device, 'f must reside on the same device as x')
         _require(f.dtype == torch.float32, 'f must be float32')
@@ -284,8 +302,28 @@ class Upfirdn2dPlugin:
         p.up_x, p.up_y, p.down_x, p.down_y = upx, upy, downx, downy
         p.pad_x0, p.pad_y0 = padx0, pady0
         p.flip, p.gain = int(bool(flip)), float(gain)
+        plain = add is None and noise is None and act is None
         with torch.cuda.device(x.device):
-            rc = load().ide3d_upfirdn2d(ctypes.byref(p), _stream(x))
+            if plain:
+                rc = load().ide3d_upfirdn2d(ctypes.byref(p), _stream(x))
+            else:
+                ep = _UpfirdnEpilogue()
+                keep = []
+                if add is not None:
+                    _require(add.shape == y.shape and add.dtype == x.dtype and add.device == x.device, 'add must match the output')
+                    ep.add, ep.add_stride = add.data_ptr(), _i64x4(add.stride())
+                if noise is not None:
+                    noise = noise.to(torch.float32).contiguous(); keep.append(noise)
+                    _require(tuple(noise.shape[-2:]) == (oh, ow) and noise.numel() == oh * ow, 'noise must be [out_h, out_w]')
+                    ep.noise, ep.noise_strength = noise.data_ptr(), float(noise_strength)
+                if act is not None:
+                    ep.fused_act, ep.act = 1, int(act)
+                    ep.alpha, ep.act_gain, ep.clamp = float(alpha), float(act_gain), float(clamp)
+                    if bias is not None:
+                        bias = bias.to(x.dtype).contiguous(); keep.append(bias)
+                        _require(bias.numel() == c, 'bias must have one entry per channel')
+                        ep.bias = bias.data_ptr()
+                rc = load().ide3d_upfirdn2d_ex(ctypes.byref(p), ctypes.byref(ep), _stream(x))
         _check(rc, 'upfirdn2d')
         return y
 

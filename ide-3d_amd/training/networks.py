@@ -33,6 +33,11 @@ _modconv_plugin = None
 use_hip_modconv = True
 
 
+def _upfirdn_plugin():
+    upfirdn2d._init()
+    return upfirdn2d._plugin
+
+
 def _modconv_init():
     global _modconv_plugin
     if _modconv_plugin is None:
@@ -56,8 +61,30 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
 
 def _demod_coefs(weight, styles):
     """d[n, o] = rsqrt(sum_{i,k} (w[o,i,k] * s[n,i])^2 + 1e-8) without materialising per-sample weights."""
-    wsq = weight.square().sum(dim=[2, 3])                 # [O, I]
-    return (styles.square() @ wsq.t() + 1e-8).rsqrt()     # [N, O]
+    if torch.is_grad_enabled() and weight.requires_grad:
+        wsq_t = weight.square().sum(dim=[2, 3]).t()       # [I, O]
+    else:
+        # sum_k w^2 only depends on the weights: cached per (storage, version), recomputed after any in-place update
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+        ent = _wsq_cache.get(id(weight))
+        if ent is None or ent[0] != key:
+            if len(_wsq_cache) > 512:
+                _wsq_cache.clear()
+            ent = (key, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
+            _wsq_cache[id(weight)] = ent
+        wsq_t = ent[1]
+    return torch.addmm(_eps_like(styles), styles.square(), wsq_t).rsqrt()     # [N, O]
+
+
+_wsq_cache = {}
+_eps_cache = {}
+
+
+def _eps_like(t):
+    k = (t.device, t.dtype)
+    if k not in _eps_cache:
+        _eps_cache[k] = torch.full([1], 1e-8, device=t.device, dtype=t.dtype)
+    return _eps_cache[k]
 
 
 @misc.profiled_function
@@ -338,6 +365,13 @@ class SynthesisLayer(torch.nn.Module):
             dcoefs = _demod_coefs(self.weight, styles)
             y = _modconv_plugin.modconv2d(x.contiguous(), self.weight.contiguous(), styles.contiguous(), dcoefs,
                                           None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
+            spec = bias_act.activation_funcs[self.activation]
+            if self.activation in ('linear', 'lrelu') and (noise is None or (noise.ndim == 2 and noise.shape == (2 * x.shape[2], 2 * x.shape[3]))):
+                # FIR + noise + bias + lrelu in one launch (ide3d_upfirdn2d_ex)
+                return _upfirdn_plugin().upfirdn2d_ex(y, self.resample_filter, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0,
+                                                      noise=noise, noise_strength=1.0, bias=self.bias, act=spec.cuda_idx,
+                                                      alpha=spec.def_alpha, act_gain=act_gain,
+                                                      clamp=(-1.0 if act_clamp is None else act_clamp))
             y = upfirdn2d.upfirdn2d(y, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
             if noise is not None:
                 y = y.add_(noise)
@@ -431,6 +465,13 @@ class SegSynthesisBlock(torch.nn.Module):
             return skip
         raise NotImplementedError
 
+    def _accumulate(self, lo, cur, y):
+        """skip = upsample2d(lo) + y  (one HIP launch when `lo` is the deferred low-resolution skip image)."""
+        if lo is not None:
+            f = self.resample_filter
+            return _upfirdn_plugin().upfirdn2d_ex(lo, f, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0, add=y)
+        return cur.add_(y) if cur is not None else y
+
     def forward(self, x, img, seg, ws, force_fp32=False, fused_modconv=None, block_noise=None, disable_rgb=False, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
@@ -455,8 +496,13 @@ class SegSynthesisBlock(torch.nn.Module):
                 x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
 
         w_shared = next(w_iter) if (self.is_last or self.architecture == 'skip') else None
-        img = self._merge_skip(img, x)
-        seg = self._merge_skip(seg, x)
+        img_lo = seg_lo = None
+        heads_follow = (self.is_last or self.architecture == 'skip') and not disable_rgb
+        if heads_follow and _inference_on_gpu(x) and img is not None and seg is not None and img.size(-1) * 2 == x.size(-1):
+            img_lo, seg_lo, img, seg = img, seg, None, None       # defer: upsample + add in one launch (_accumulate)
+        else:
+            img = self._merge_skip(img, x)
+            seg = self._merge_skip(seg, x)
         if self.is_last or self.architecture == 'skip':
             if disable_rgb:
                 img = seg = None
@@ -467,8 +513,8 @@ class SegSynthesisBlock(torch.nn.Module):
                 else:
                     y = self.torgb(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
                     y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
-                img = img.add_(y) if img is not None else y
-                seg = seg.add_(y_seg) if seg is not None else y_seg
+                img = self._accumulate(img_lo, img, y)
+                seg = self._accumulate(seg_lo, seg, y_seg)
         assert x.dtype == dtype
         assert img is None or img.dtype == torch.float32
         assert seg is None or seg.dtype == torch.float32

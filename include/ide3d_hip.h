@@ -83,6 +83,28 @@ typedef struct ide3d_upfirdn2d_params {
 
 int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* p, void* stream);
 
+/*
+ * upfirdn2d with a fused epilogue (MI355X extension; saves the HBM round trips of the element-wise ops that always
+ * follow the FIR on the render path):
+ *   y = bias_act( FIR(x) + add + noise * noise_strength )
+ * `add` (same dtype as x, element strides) fuses the skip accumulation `img = upsample2d(img) + torgb(x)`
+ * (inversion/networks.py:1100-1111); `noise` [out_h, out_w] float32 + `bias` [c] + act fuse the tail of an
+ * up-sampling SynthesisLayer, `x.add_(noise)` and `bias_act(x, b, act='lrelu', gain, clamp)` (networks.py:507-512).
+ * Any pointer may be NULL; fused_act = 0 skips the bias/activation stage.  act: 1 linear, 3 lrelu.
+ */
+typedef struct ide3d_upfirdn2d_epilogue {
+    const void*  add;
+    int64_t      add_stride[4];
+    const float* noise;
+    float        noise_strength;
+    const void*  bias;
+    int32_t      fused_act;
+    int32_t      act;
+    float        alpha, act_gain, clamp;
+} ide3d_upfirdn2d_epilogue;
+
+int ide3d_upfirdn2d_ex(const ide3d_upfirdn2d_params* p, const ide3d_upfirdn2d_epilogue* ep, void* stream);
+
 /* ---- filtered_lrelu ------------------------------------------------------------------- */
 /*
  * Replaces `_plugin.filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy,
