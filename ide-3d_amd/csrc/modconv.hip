@@ -28,6 +28,7 @@
 //     workspace, `modconv_epilogue_kernel` reduces them and applies the epilogue — deterministic, no atomics.
 // Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
 #include "common.h"
+#include <stdlib.h>
 
 namespace ide3d {
 
@@ -42,16 +43,18 @@ template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9
 
 template <int MODE, int BIG, int TI, int PH, int PW>
 struct McCfg {
-    static_assert(TI * PH * PW == 128, "pixel tile must hold 128 pixels");
+    static constexpr int BN = TI * PH * PW;
+    static_assert(BN == 128 || BN == 256, "pixel tile must hold 128 or 256 pixels");
     using MC = ModeCfg<MODE>;
     static constexpr int KC = MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
     static constexpr int WM = BIG ? 2 : 1, WN = 4 / WM;
     static constexpr int MTW = BIG ? 2 : 1;                 // 32-row M tiles per wave
-    static constexpr int NTW = 4 / WN;                      // 32-pixel N tiles per wave
+    static constexpr int NTW = (BN / 32) / WN;              // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
     static constexpr int HALO = (MODE == MODE_CONV1) ? 0 : 1;
     static constexpr int HP = PH + 2 * HALO, HW = PW + 2 * HALO;   // (halo) patch
-    static constexpr int XW = (MODE == MODE_CONV1) ? PW : HW + 2;  // LDS row pitch
+    // LDS row pitch: with 16-pixel rows a pitch = 16 (mod 32) puts the two pixel rows of an MFMA N tile on disjoint banks
+    static constexpr int XW = (MODE == MODE_CONV1) ? PW : ((PW == 16) ? 48 : HW + 2);
     static constexpr int XS = HP * XW;                      // per-channel pitch
     static constexpr int XI = KC * XS;                      // per-image pitch
     static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
@@ -101,6 +104,7 @@ struct ConvGeom {
     int img_groups;                 // ceil(n / TI)
     int mblocks, cchunks, split_k, chunks_per_split;
     int oh, ow;                     // output size
+    int debug;                      // experiments only: 1 = no staging after the first chunk, 2 = staging but no MFMA
 };
 
 template <int MODE, int BIG, int TI, int PH, int PW>
@@ -197,17 +201,22 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 
     // Staging is split into an issue-only half (unconditional loads from clamped addresses: no exec-mask
     // branches, no vmcnt(0) between loads) and a commit half that runs after the MFMAs of the current chunk.
-    float4 wreg[K::NW4];
     float xreg[K::NXE], sreg[K::NXE];
-    const int wq_lim = ntaps * (K::KC * K::BM / 4);
     const int img_last = p.n - 1;
-    auto fetch = [&](int c) {
+    constexpr int PIECE = (K::KC * K::BM < 256) ? K::KC * K::BM : 256;   // floats per LDS-DMA piece (<= 64 lanes x 16 B)
+    constexpr int PPT = K::KC * K::BM / PIECE;                            // pieces per tap slab
+    const int w_pieces = ntaps * PPT;
+    // Weights: global -> LDS by DMA (global_load_lds_dwordx4): the packed slab is already the LDS image, so there is no
+    // VGPR round trip and no ds_write; each wave moves every 4th piece.  Input patch: issue-only loads into
+    // registers (clamped addresses, no branches); scaling by the styles and zero fill happen in commit().
+    auto fetch = [&](int c, int buf) {
         const float* ws = wsrc + (int64_t)c * (K::WTAPS * K::KC * K::BM);
-#pragma unroll
-        for (int i = 0; i < K::NW4; ++i) {
-            const int q = min(tid + i * 256, wq_lim - 1);                  // float4 index inside the staged slab
-            const int t = q / (K::KC * K::BM / 4), rq = q - t * (K::KC * K::BM / 4);
-            wreg[i] = *reinterpret_cast<const float4*>(ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + rq * 4);
+        for (int i = wid; i < w_pieces; i += 4) {
+            const int t = i / PPT, r = (i - t * PPT) * PIECE;
+            const float* src = ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + r + lane * 4;
+            if (lane * 4 < PIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(&s_w[buf][t * (K::KC * K::BM) + r]), 16, 0, 0);
         }
         const int ci0 = c * K::KC;
 #pragma unroll
@@ -220,11 +229,6 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         }
     };
     auto commit = [&](int buf, int c) {
-#pragma unroll
-        for (int i = 0; i < K::NW4; ++i) {
-            const int q = tid + i * 256;
-            if (q < wq_lim) *reinterpret_cast<float4*>(&s_w[buf][q * 4]) = wreg[i];
-        }
         const int ci0 = c * K::KC;
 #pragma unroll
         for (int i = 0; i < K::NXE; ++i) {
@@ -235,13 +239,13 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     };
 
     if (c_begin < c_end) {
-        fetch(c_begin);
+        fetch(c_begin, 0);
         commit(0, c_begin);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) fetch(c + 1);
+        if (c + 1 < c_end && g.debug != 1) fetch(c + 1, buf ^ 1);
         const float* sw = s_w[buf];
         const float* sx = s_x[buf];
         auto tap_body = [&](int t, int off) {
@@ -265,8 +269,8 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 #pragma unroll
             for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t]);
         }
-        if (c + 1 < c_end) commit(buf ^ 1, c + 1);
-        __syncthreads();
+        if (c + 1 < c_end && g.debug != 1) commit(buf ^ 1, c + 1);
+        if (g.debug != 1) __syncthreads();
     }
 
     // ---- epilogue ----
@@ -353,7 +357,13 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     }
     const int mind = (p.h < p.w_) ? p.h : p.w_;
     pl.tile = (mind >= 12 || p.w_batch_stride) ? 0 : (mind >= 6 ? 1 : 2);     // per-image weights need one image per tile
-    static const int TIv[3] = {1, 2, 8}, PHv[3] = {8, 8, 4}, PWv[3] = {16, 8, 4};
+    // 256-pixel tiles (8 accumulators per wave) for big-cout 3x3 layers with enough work to fill the chip twice over
+    if (pl.tile == 0 && pl.big && pl.mode != MODE_CONV1 && !p.w_batch_stride) {
+        const int64_t blocks256 = (int64_t)pl.mblocks * cdiv(gh[0], 16) * cdiv(gw[0], 16) * p.n * ((pl.mode == MODE_TCONV3) ? 4 : 1);
+        if (blocks256 >= 2 * kNumCU) pl.tile = 3;
+    }
+    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (!pl.big || pl.mode == MODE_CONV1)) ? 0 : t; }
+    static const int TIv[4] = {1, 2, 8, 1}, PHv[4] = {8, 8, 4, 16}, PWv[4] = {16, 8, 4, 16};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -362,6 +372,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     }
     g.img_groups = cdiv(p.n, TIv[pl.tile]);
     g.mblocks = pl.mblocks; g.cchunks = pl.cchunks; g.oh = pl.oh; g.ow = pl.ow;
+    g.debug = getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0;
     const int64_t base_blocks = (int64_t)g.mblocks * g.tile_base[4] * g.img_groups;
     int split = 1;
     if (base_blocks < 512 && pl.cchunks >= 8) {
@@ -381,7 +392,9 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     if (pl.tile == 0)      hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
-    else                   hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    else if (pl.tile == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    else if constexpr (BIG && MODE != MODE_CONV1)
+        hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
 }
 
 }  // namespace ide3d
