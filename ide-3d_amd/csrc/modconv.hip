@@ -29,26 +29,32 @@
 // Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace ide3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2 };
+enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3 };
 
 template <int MODE> struct ModeCfg;
 template <> struct ModeCfg<MODE_CONV3>  { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 template <> struct ModeCfg<MODE_CONV1>  { static constexpr int KC = 16, WTAPS = 1, MAXT = 1; };
 template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9, MAXT = 4; };
+// all-class transposed conv: one block computes the four output parity classes of its grid tile from ONE staged input
+// patch and all 9 taps (each tap feeds exactly one class), i.e. 4x the MFMA work per staging step / barrier of mode 2.
+template <> struct ModeCfg<MODE_TCONV3A> { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 
 template <int MODE, int BIG, int TI, int PH, int PW>
 struct McCfg {
     static constexpr int BN = TI * PH * PW;
-    static_assert(BN == 128 || BN == 256, "pixel tile must hold 128 or 256 pixels");
+    static_assert(BN == 64 || BN == 128 || BN == 256, "pixel tile must hold 64, 128 or 256 pixels");
+    static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;   // accumulator sets (output parity classes)
     using MC = ModeCfg<MODE>;
     static constexpr int KC = MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
+    // BIG: 1 -> BM 128 (waves 2 x 2, two M tiles each); 2 -> BM 64 (waves 2 x 2, one M tile each); 0 -> BM 32 (waves 1 x 4)
     static constexpr int WM = BIG ? 2 : 1, WN = 4 / WM;
-    static constexpr int MTW = BIG ? 2 : 1;                 // 32-row M tiles per wave
+    static constexpr int MTW = (BIG == 1) ? 2 : 1;          // 32-row M tiles per wave
     static constexpr int NTW = (BN / 32) / WN;              // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
     static constexpr int HALO = (MODE == MODE_CONV1) ? 0 : 1;
@@ -71,7 +77,7 @@ __device__ __forceinline__ int sel(const int (&a)[N], int t) {
     return v;
 }
 
-__host__ __device__ inline int mc_bm(int cout) { return cout > 96 ? 128 : 32; }
+__host__ __device__ inline int mc_bm(int cout) { return cout > 96 ? 128 : (cout > 32 ? 64 : 32); }
 __host__ __device__ inline int mc_kc(int k) { return k == 3 ? 4 : 16; }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,7 +114,7 @@ struct ConvGeom {
 };
 
 template <int MODE, int BIG, int TI, int PH, int PW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (MODE == MODE_TCONV3A) ? 3 : 2)
 modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
     using K = McCfg<MODE, BIG, TI, PH, PW>;
     __shared__ __attribute__((aligned(16))) float s_w[2][K::LDS_W];
@@ -141,6 +147,13 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         for (int t = 0; t < 9; ++t) { t_widx[t] = t; t_off[t] = (t / 3) * K::XW + (t % 3); }
     } else if (MODE == MODE_CONV1) {
         ntaps = 1; t_widx[0] = 0; t_off[0] = 0;
+    } else if (MODE == MODE_TCONV3A) {
+        ntaps = 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            t_widx[t] = t; t_off[t] = ((ky == 2) ? 0 : 1) * K::XW + ((kx == 2) ? 0 : 1);
+        }
     } else {
         // out[2i+ky] += x[i] w[ky]:  even output rows take ky = 0 (i = c) and ky = 2 (i = c-1); odd rows ky = 1 (i = c).
         // patch row of input i for grid row c (patch origin = y0 - 1): (c - y0) + 1 + (i - c).
@@ -178,13 +191,15 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     }
     const int hw = p.h * p.w_;
 
-    f32x16 acc[K::MTW][K::NTW];
+    f32x16 acc[K::NCLS][K::MTW][K::NTW];
 #pragma unroll
-    for (int i = 0; i < K::MTW; ++i)
+    for (int q = 0; q < K::NCLS; ++q)
 #pragma unroll
-        for (int j = 0; j < K::NTW; ++j)
+        for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < K::NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
     // B-operand base address of this lane per N tile: pixel j -> (ti, py, px)
     int boff[K::NTW];
@@ -248,7 +263,8 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         if (c + 1 < c_end && g.debug != 1) fetch(c + 1, buf ^ 1);
         const float* sw = s_w[buf];
         const float* sx = s_x[buf];
-        auto tap_body = [&](int t, int off) {
+        auto tap_body = [&](int t, int off, auto cls_tag) {
+            constexpr int q = decltype(cls_tag)::value;
 #pragma unroll
             for (int cp = 0; cp < K::KC / 2; ++cp) {
                 float a[K::MTW], b[K::NTW];
@@ -260,14 +276,22 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
                 for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
                     for (int j = 0; j < K::NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[q][i][j], 0, 0, 0);
             }
         };
-        if (MODE == MODE_TCONV3) {
-            for (int t = 0; t < ntaps; ++t) tap_body(t, sel(t_off, t));
+        using C0 = std::integral_constant<int, 0>;
+        if constexpr (MODE == MODE_TCONV3) {
+            for (int t = 0; t < ntaps; ++t) tap_body(t, sel(t_off, t), C0{});
+        } else if constexpr (MODE == MODE_TCONV3A) {
+            // tap (ky, kx) feeds output parity class (ky & 1, kx & 1)
+            tap_body(0, t_off[0], std::integral_constant<int, 0>{}); tap_body(1, t_off[1], std::integral_constant<int, 1>{});
+            tap_body(2, t_off[2], std::integral_constant<int, 0>{}); tap_body(3, t_off[3], std::integral_constant<int, 2>{});
+            tap_body(4, t_off[4], std::integral_constant<int, 3>{}); tap_body(5, t_off[5], std::integral_constant<int, 2>{});
+            tap_body(6, t_off[6], std::integral_constant<int, 0>{}); tap_body(7, t_off[7], std::integral_constant<int, 1>{});
+            tap_body(8, t_off[8], std::integral_constant<int, 0>{});
         } else {
 #pragma unroll
-            for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t]);
+            for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t], C0{});
         }
         if (c + 1 < c_end && g.debug != 1) commit(buf ^ 1, c + 1);
         if (g.debug != 1) __syncthreads();
@@ -276,13 +300,16 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     // ---- epilogue ----
     const bool raw = (g.split_k > 1);
 #pragma unroll
+    for (int q = 0; q < K::NCLS; ++q)
+#pragma unroll
     for (int j = 0; j < K::NTW; ++j) {
         const int pix = (wn * K::NTW + j) * 32 + l32;
         const int ti = pix / (PH * PW), rem = pix % (PH * PW);
         const int n = n0 + ti;
         const int gy = y0 + rem / PW, gx = x0 + rem % PW;              // (class-)grid coordinates
-        const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy;
-        const int ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
+        const int qy = (MODE == MODE_TCONV3A) ? (q >> 1) : cpy, qx = (MODE == MODE_TCONV3A) ? (q & 1) : cpx;
+        const int oy = (MODE == MODE_TCONV3 || MODE == MODE_TCONV3A) ? 2 * gy + qy : gy;
+        const int ox = (MODE == MODE_TCONV3 || MODE == MODE_TCONV3A) ? 2 * gx + qx : gx;
         const bool ok = n < p.n && oy < g.oh && ox < g.ow;
         if (!ok) continue;
         const float nz = (!raw && p.noise) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
@@ -294,7 +321,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int co = mb * K::BM + (wm * K::MTW + i) * 32 + row;
                 if (co >= p.cout) continue;
-                float v = acc[i][j][r];
+                float v = acc[q][i][j][r];
                 if (!raw) {
                     if (p.dcoefs) v *= p.dcoefs[(int64_t)n * p.cout + co];
                     v += nz;
@@ -342,28 +369,33 @@ struct ConvPlan {
 
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
-    pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128;
+    const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !getenv("IDE3D_MODCONV_NO_TCONV3A");
+    if (allcls) pl.mode = MODE_TCONV3A;
+    pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
-    pl.oh = (pl.mode == MODE_TCONV3) ? 2 * p.h + 1 : p.h;
-    pl.ow = (pl.mode == MODE_TCONV3) ? 2 * p.w_ + 1 : p.w_;
+    const bool transposed = (pl.mode == MODE_TCONV3 || pl.mode == MODE_TCONV3A);
+    pl.oh = transposed ? 2 * p.h + 1 : p.h;
+    pl.ow = transposed ? 2 * p.w_ + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
     for (int c = 0; c < 4; ++c) {
         if (pl.mode == MODE_TCONV3) { gh[c] = (c >> 1) ? p.h : p.h + 1; gw[c] = (c & 1) ? p.w_ : p.w_ + 1; }
+        else if (pl.mode == MODE_TCONV3A) { gh[c] = p.h + 1; gw[c] = p.w_ + 1; }
         else { gh[c] = p.h; gw[c] = p.w_; }
     }
     const int mind = (p.h < p.w_) ? p.h : p.w_;
     pl.tile = (mind >= 12 || p.w_batch_stride) ? 0 : (mind >= 6 ? 1 : 2);     // per-image weights need one image per tile
     // 256-pixel tiles (8 accumulators per wave) for big-cout 3x3 layers with enough work to fill the chip twice over
-    if (pl.tile == 0 && pl.big && pl.mode != MODE_CONV1 && !p.w_batch_stride) {
+    if (pl.tile == 0 && pl.big == 1 && pl.mode != MODE_CONV1 && !p.w_batch_stride) {
         const int64_t blocks256 = (int64_t)pl.mblocks * cdiv(gh[0], 16) * cdiv(gw[0], 16) * p.n * ((pl.mode == MODE_TCONV3) ? 4 : 1);
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
-    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (!pl.big || pl.mode == MODE_CONV1)) ? 0 : t; }
-    static const int TIv[4] = {1, 2, 8, 1}, PHv[4] = {8, 8, 4, 16}, PWv[4] = {16, 8, 4, 16};
+    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1)) ? 0 : t; }
+    if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
+    static const int TIv[5] = {1, 2, 8, 1, 1}, PHv[5] = {8, 8, 4, 16, 4}, PWv[5] = {16, 8, 4, 16, 16};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -390,10 +422,14 @@ template <int MODE, int BIG>
 static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
+    if constexpr (MODE == MODE_TCONV3A) {
+        if constexpr (BIG != 0)
+            hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    } else
     if (pl.tile == 0)      hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
-    else if constexpr (BIG && MODE != MODE_CONV1)
+    else if constexpr (BIG == 1 && MODE != MODE_CONV1)
         hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
 }
 
@@ -436,9 +472,14 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         hipLaunchKernelGGL(modconv_pack_kernel, dim3(stream_grid(pl.packed_floats, 256)), dim3(256), 0, st,
                            p.w, p.w_batch_stride, p.w_batch_stride ? p.n : 1, p.cout, p.cin, pl.taps, pl.bm, pl.kc, pl.mblocks, pl.cchunks, wp);
     }
-    if (pl.mode == MODE_CONV3)       { if (pl.big) launch_tiles<MODE_CONV3, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV3, 0>(p, pl, wp, partial, st); }
-    else if (pl.mode == MODE_CONV1)  { if (pl.big) launch_tiles<MODE_CONV1, 1>(p, pl, wp, partial, st);  else launch_tiles<MODE_CONV1, 0>(p, pl, wp, partial, st); }
-    else                             { if (pl.big) launch_tiles<MODE_TCONV3, 1>(p, pl, wp, partial, st); else launch_tiles<MODE_TCONV3, 0>(p, pl, wp, partial, st); }
+#define IDE3D_MC_DISPATCH(M) \
+    do { if (pl.big == 1) launch_tiles<M, 1>(p, pl, wp, partial, st); else if (pl.big == 2) launch_tiles<M, 2>(p, pl, wp, partial, st); \
+         else launch_tiles<M, 0>(p, pl, wp, partial, st); } while (0)
+    if (pl.mode == MODE_CONV3)       IDE3D_MC_DISPATCH(MODE_CONV3);
+    else if (pl.mode == MODE_CONV1)  IDE3D_MC_DISPATCH(MODE_CONV1);
+    else if (pl.mode == MODE_TCONV3A) IDE3D_MC_DISPATCH(MODE_TCONV3A);
+    else                             IDE3D_MC_DISPATCH(MODE_TCONV3);
+#undef IDE3D_MC_DISPATCH
     if (pl.g.split_k > 1) {
         const int64_t per = (int64_t)p.n * p.cout * pl.oh * pl.ow;
         hipLaunchKernelGGL(modconv_epilogue_kernel, dim3(stream_grid(per, 256)), dim3(256), 0, st, p, partial, pl.g.split_k, pl.oh, pl.ow);

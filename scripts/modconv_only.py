@@ -21,3 +21,17 @@ for (n, cin, cout, res, k) in ((4, 128, 128, 256, 3), (4, 512, 512, 64, 3), (4, 
     ms = e0.elapsed_time(e1) / iters
     fl = 2 * cin * cout * k * k * res * res * n
     print(f'modconv n={n} {cin}->{cout} @{res} k={k}: {ms*1e3:.1f} us, {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)')
+print('--- transposed 3x3 stride 2 (mode 2) ---')
+for (n, cin, cout, res) in ((4, 512, 256, 64), (4, 256, 128, 128), (4, 128, 64, 256), (4, 512, 512, 32)):
+    x = torch.randn(n, cin, res, res, generator=g).to(dev); w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    s = (torch.randn(n, cin, generator=g) + 1).to(dev); d = torch.rand(n, cout, generator=g).to(dev)
+    f = lambda: hip_plugin.ModconvPlugin.modconv2d(x, w, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2 * cin * cout * 9 * res * res * n
+    print(f'tconv n={n} {cin}->{cout} in@{res}: {ms*1e3:.1f} us, {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)')
