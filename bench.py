@@ -141,6 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -171,12 +172,23 @@ def main():
     palette = dr.palette_tensor(spec.seg_channels, device)
     gathered = [torch.empty([BATCH, 512, 1024, 3], dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
 
+    graphed = None
+    if args.graph:
+        try:
+            graphed = triplane.GraphedRenderer(G, BATCH, device)
+        except Exception as e:      # capture is an optimisation, never a requirement
+            print(f'[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            graphed = None
+
     def step(i):
         seeds = [(i * world + rank) * BATCH + j for j in range(BATCH)]
         z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in seeds])).to(device)
         with torch.no_grad():
-            ws = G.mapping(z, cond)
-            img, seg = G.synthesis(ws, c=cams, noise_mode='const', return_seg=True)
+            if graphed is not None:
+                img, seg = graphed(z, cond, cams)
+            else:
+                ws = G.mapping(z, cond)
+                img, seg = G.synthesis(ws, c=cams, noise_mode='const', return_seg=True)
             frames = dr.frames_u8(img, seg, palette)
         if dist:
             dist.gather(frames, gathered, dst=0)
@@ -210,7 +222,7 @@ def main():
                        'global_batch': BATCH * world, 'parallelism': f'dp{world} (one rank per GPU, RCCL gather of uint8 frames)'},
             'frames_per_s_per_gpu': frames_total / dt / world,
             'conv_tflops': conv_flops(spec, BATCH) * args.steps / dt / 1e12,
-            'native_launches': dict(hip_plugin.CALLS),
+            'native_launches': dict(hip_plugin.CALLS), 'hip_graph': graphed is not None,
         }
         if not args.no_roofline:
             out['roofline'] = bench_gather(device)
