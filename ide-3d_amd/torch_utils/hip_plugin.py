@@ -175,6 +175,8 @@ def load():
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
             'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32, i32],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+            'ide3d_style_demod': [vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp],
+            'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
         }
         for name, argtypes in protos.items():
             fn = getattr(lib, name)          # AttributeError here = header / library mismatch
@@ -188,7 +190,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
-    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8',
+    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
 )
 
 
@@ -630,6 +632,44 @@ class ModconvPlugin:
         return y
 
 
+class StylePlugin:
+    @staticmethod
+    def style_demod(w, affine_w, affine_b, affine_gain, bias_gain, wsq_t=None):
+        """w [n, wdim] (rows may be strided), affine_w [cin, wdim], wsq_t [cin, cout] | None -> (styles [n, cin], dcoefs [n, cout] | None)."""
+        _require(w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1, 'style_demod: w must be float32 [n, wdim] with unit inner stride')
+        n, wdim = w.shape
+        cin = affine_w.shape[0]
+        _require(affine_w.is_contiguous() and affine_w.dtype == torch.float32 and affine_w.shape[1] == wdim, 'style_demod: bad affine weight')
+        styles = torch.empty([n, cin], dtype=torch.float32, device=w.device)
+        dcoefs = None
+        cout = 0
+        if wsq_t is not None:
+            _require(wsq_t.is_contiguous() and wsq_t.shape[0] == cin, 'style_demod: wsq_t must be contiguous [cin, cout]')
+            cout = wsq_t.shape[1]
+            dcoefs = torch.empty([n, cout], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = load().ide3d_style_demod(_ptr(w), w.stride(0), _ptr(affine_w), _ptr(affine_b), _ptr(wsq_t), n, cin, cout, wdim,
+                                          float(affine_gain), float(bias_gain), _ptr(styles), _ptr(dcoefs), _stream(w))
+        _check(rc, 'style_demod')
+        return styles, dcoefs
+
+    @staticmethod
+    def fold_heads(w, affine_gain, a0, b0, w0, gain0, a1, b1, w1, gain1):
+        """-> per-image folded head weights [n, cout0 + cout1, cin, 1, 1]."""
+        _require(w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1, 'fold_heads: w must be float32 [n, wdim]')
+        n, wdim = w.shape
+        cout0, cin = w0.shape[0], w0.shape[1]
+        cout1 = w1.shape[0]
+        for t in (a0, b0, w0, a1, b1, w1):
+            _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'fold_heads: contiguous float32 CUDA tensors required')
+        out = torch.empty([n, cout0 + cout1, cin, 1, 1], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = load().ide3d_fold_heads(_ptr(w), w.stride(0), n, cin, wdim, float(affine_gain), _ptr(a0), _ptr(b0), _ptr(w0), cout0, float(gain0),
+                                         _ptr(a1), _ptr(b1), _ptr(w1), cout1, float(gain1), _ptr(out), _stream(w))
+        _check(rc, 'fold_heads')
+        return out
+
+
 class FramePlugin:
     @staticmethod
     def frame_u8(img, seg, palette):
@@ -653,4 +693,5 @@ PLUGINS = {
     'volume_render_plugin': VolumeRenderPlugin,
     'modconv_plugin': ModconvPlugin,
     'frame_plugin': FramePlugin,
+    'style_plugin': StylePlugin,
 }

@@ -38,6 +38,39 @@ def _upfirdn_plugin():
     return upfirdn2d._plugin
 
 
+_style_plugin = None
+
+
+def _style_init():
+    global _style_plugin
+    if _style_plugin is None:
+        _style_plugin = custom_ops.get_plugin(module_name='style_plugin', sources=['style.hip'])
+    return True
+
+
+def _wsq_t(weight):
+    """[Cin, Cout] = sum_k W[o, i, k]^2 transposed, cached per weight version (inference only)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    ent = _wsq_cache.get(id(weight))
+    if ent is None or ent[0] != key:
+        if len(_wsq_cache) > 512:
+            _wsq_cache.clear()
+        ent = (key, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
+        _wsq_cache[id(weight)] = ent
+    return ent[1]
+
+
+def _styles_and_dcoefs(affine, w, weight, demodulate):
+    """(styles, dcoefs) of a modulated conv: ONE HIP launch (csrc/style.hip) in inference on device tensors,
+    otherwise the PyTorch definition."""
+    if (_inference_on_gpu(w, affine.weight, weight) and w.ndim == 2 and w.stride(1) == 1 and affine.activation == 'linear'
+            and affine.bias is not None and _style_init()):
+        return _style_plugin.style_demod(w, affine.weight, affine.bias, affine.weight_gain, affine.bias_gain,
+                                         _wsq_t(weight) if demodulate else None)
+    styles = affine(w)
+    return styles, (_demod_coefs(weight, styles) if demodulate else None)
+
+
 def _modconv_init():
     global _modconv_plugin
     if _modconv_plugin is None:
@@ -152,7 +185,7 @@ def modulated_conv2d(
     return x
 
 
-def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bias, act, gain, clamp):
+def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bias, act, gain, clamp, dcoefs=None):
     """Stride-1 modulated conv + noise + bias + activation in one HIP launch (inference only).
     Returns None when the fused kernel does not apply."""
     cout, cin, kh, kw = weight.shape
@@ -160,7 +193,8 @@ def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bi
             and _inference_on_gpu(x, weight, styles, bias) and _modconv_init()):
         return None
     spec = bias_act.activation_funcs[act]
-    dcoefs = _demod_coefs(weight, styles) if demodulate else None
+    if demodulate and dcoefs is None:
+        dcoefs = _demod_coefs(weight, styles)
     return _modconv_plugin.modconv2d(
         x.contiguous(), weight.contiguous(), styles.contiguous(), dcoefs, noise2d, noise_strength, bias,
         spec.cuda_idx, spec.def_alpha, gain, -1.0 if clamp is None else clamp)
@@ -175,13 +209,18 @@ def _dual_head(x, torgb, toseg, w):
             and _inference_on_gpu(x, w, torgb.weight, toseg.weight) and _modconv_init()):
         return None
     n = x.shape[0]
-    s_rgb = torgb.affine(w) * torgb.weight_gain
-    s_seg = toseg.affine(w) * toseg.weight_gain
-    if s_rgb.shape[0] != n:
+    if w.shape[0] != n:
         return None
-    wr = torgb.weight[None, :, :, 0, 0] * s_rgb[:, None, :]           # [N, Co_rgb, Cin]
-    ws = toseg.weight[None, :, :, 0, 0] * s_seg[:, None, :]
-    wcat = torch.cat([wr, ws], dim=1)[:, :, :, None, None].contiguous()
+    if w.ndim == 2 and w.stride(1) == 1 and _style_init():
+        wcat = _style_plugin.fold_heads(w, torgb.affine.weight_gain,
+                                        torgb.affine.weight, torgb.affine.bias, torgb.weight.reshape(torgb.weight.shape[0], -1), torgb.weight_gain,
+                                        toseg.affine.weight, toseg.affine.bias, toseg.weight.reshape(toseg.weight.shape[0], -1), toseg.weight_gain)
+    else:
+        s_rgb = torgb.affine(w) * torgb.weight_gain
+        s_seg = toseg.affine(w) * toseg.weight_gain
+        wr = torgb.weight[None, :, :, 0, 0] * s_rgb[:, None, :]           # [N, Co_rgb, Cin]
+        ws = toseg.weight[None, :, :, 0, 0] * s_seg[:, None, :]
+        wcat = torch.cat([wr, ws], dim=1)[:, :, :, None, None].contiguous()
     bias = torch.cat([torgb.bias, toseg.bias]).to(x.dtype)
     clamp = -1.0 if torgb.conv_clamp is None else torgb.conv_clamp
     y = _modconv_plugin.modconv2d(x.contiguous(), wcat, None, None, None, 0.0, bias, 1, 0.0, 1.0, clamp)
@@ -337,8 +376,9 @@ class SynthesisLayer(torch.nn.Module):
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, input_noise=None, **unused_kwargs):
         assert noise_mode in ['random', 'const', 'none']
-        styles = self.affine(w)
+        styles, dcoefs_pre = _styles_and_dcoefs(self.affine, w, self.weight, True)
         if styles.size(0) < x.size(0):
+            dcoefs_pre = None
             assert x.size(0) % styles.size(0) == 0
             styles = styles.repeat_interleave(x.size(0) // styles.size(0), dim=0)
 
@@ -362,7 +402,7 @@ class SynthesisLayer(torch.nn.Module):
                 and _inference_on_gpu(x, self.weight, styles, self.bias) and _modconv_init()):
             # up-sampling layer, MI355X inference path (same strategy as conv2d_resample.py:112-129): transposed
             # 3x3 stride-2 conv as a parity-class implicit GEMM (demodulation fused), then the 4x4 FIR with gain 4.
-            dcoefs = _demod_coefs(self.weight, styles)
+            dcoefs = dcoefs_pre if dcoefs_pre is not None else _demod_coefs(self.weight, styles)
             y = _modconv_plugin.modconv2d(x.contiguous(), self.weight.contiguous(), styles.contiguous(), dcoefs,
                                           None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
             spec = bias_act.activation_funcs[self.activation]
@@ -381,7 +421,7 @@ class SynthesisLayer(torch.nn.Module):
             if noise is None or (const_noise and input_noise is None and noise.shape == x.shape[2:]):
                 # `noise` already carries noise_strength (device-side product: no host sync)
                 y = _modconv_bias_act(x, self.weight, styles, True, noise, 1.0,
-                                      self.bias.to(x.dtype), self.activation, act_gain, act_clamp)
+                                      self.bias.to(x.dtype), self.activation, act_gain, act_clamp, dcoefs=dcoefs_pre)
                 if y is not None:
                     return y
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,

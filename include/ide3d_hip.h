@@ -296,6 +296,28 @@ int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int3
                                       int32_t per_image_weights);
 int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
 
+/* ---- per-layer style preparation ------------------------------------------------------------------ */
+/*
+ * One launch for what precedes a modulated convolution in inference (inversion/networks.py:432, :91-93):
+ *   styles[n, :] = (w[n, :] @ affine_w^T) * affine_gain + affine_b * bias_gain          FullyConnectedLayer, :152-165
+ *   dcoefs[n, o] = rsqrt( sum_i styles[n, i]^2 * wsq_t[i, o] + 1e-8 ),  wsq_t[i, o] = sum_k W[o, i, k]^2
+ * w: rows of `wdim` floats, `w_stride` apart; affine_w [cin, wdim]; affine_b [cin] or NULL; wsq_t [cin, cout];
+ * dcoefs may be NULL (no demodulation).
+ */
+int ide3d_style_demod(const float* w, int64_t w_stride, const float* affine_w, const float* affine_b, const float* wsq_t,
+                      int32_t n, int32_t cin, int32_t cout, int32_t wdim, float affine_gain, float bias_gain,
+                      float* styles, float* dcoefs, void* stream);
+
+/*
+ * Per-image folded weights of the two heads of a dual-path block (toRGB + toSeg share w, networks.py:1093-1130):
+ *   out[n, o, i] = W_h[o, i] * (affine_h(w[n]) [i] * gain_h),  h = 0 for o < cout0 else 1;  out [n, cout0 + cout1, cin].
+ * Feeds ide3d_modconv2d with w_batch_stride > 0 so that both 1x1 heads are one launch.
+ */
+int ide3d_fold_heads(const float* w, int64_t w_stride, int32_t n, int32_t cin, int32_t wdim, float affine_gain,
+                     const float* a0, const float* b0, const float* w0, int32_t cout0, float gain0,
+                     const float* a1, const float* b1, const float* w1, int32_t cout1, float gain1,
+                     float* out, void* stream);
+
 /* ---- output post-processing -------------------------------------------- */
 /*
  * `mask2color(seg)` (dnnlib/seg_tools.py:75-81: argmax over the class channel + palette) and
