@@ -38,25 +38,29 @@ __device__ __forceinline__ void affine_rows(const float* __restrict__ wv, const 
     }
 }
 
-// grid: (ceil(cout / 64), n).  wsq_t [cin, cout] = sum_k W^2 transposed.  Block (0, n) also stores styles[n].
-__global__ void __launch_bounds__(1024)
-style_demod_kernel(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
-                   const float* __restrict__ wsq_t, int n, int cin, int cout, int wdim, float a_gain, float b_gain,
-                   float* __restrict__ styles, float* __restrict__ dcoefs) {
+// phase A, grid (ceil(cin / STYLE_ROWS), n): styles[n, rows of this block].
+constexpr int STYLE_ROWS = 64;
+
+__global__ void __launch_bounds__(512)
+style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
+                    int cin, int wdim, float a_gain, float b_gain, float* __restrict__ styles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_w = lds;                 // [wdim]
-    float* s_s = lds + wdim;          // [cin]  styles, then squared
-    float* s_p = s_s + cin;           // [16][64] partial sums
-    const int img = blockIdx.y;
+    float* s_w = lds;
+    const int img = blockIdx.y, i0 = blockIdx.x * STYLE_ROWS;
+    const int rows = min(STYLE_ROWS, cin - i0);
     for (int k = threadIdx.x; k < wdim; k += blockDim.x) s_w[k] = w[(int64_t)img * w_stride + k];
     __syncthreads();
-    affine_rows(s_w, A, b, cin, wdim, a_gain, b_gain, 1.0f, s_s);
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < cin; i += blockDim.x) styles[(int64_t)img * cin + i] = s_s[i];
-    if (dcoefs == nullptr) return;
-    __syncthreads();
-    for (int i = threadIdx.x; i < cin; i += blockDim.x) s_s[i] = s_s[i] * s_s[i];
+    affine_rows(s_w, A + (int64_t)i0 * wdim, b ? b + i0 : nullptr, rows, wdim, a_gain, b_gain, 1.0f, styles + (int64_t)img * cin + i0);
+}
+
+// phase B, grid (ceil(cout / 64), n): dcoefs[n, o] = rsqrt(sum_i styles[n, i]^2 * wsq_t[i, o] + 1e-8); wsq_t [cin, cout].
+__global__ void __launch_bounds__(1024)
+style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq_t, int cin, int cout, float* __restrict__ dcoefs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_s = lds;                 // [cin] squared styles
+    float* s_p = lds + cin;           // [16][64] partial sums
+    const int img = blockIdx.y;
+    for (int i = threadIdx.x; i < cin; i += blockDim.x) { const float v = styles[(int64_t)img * cin + i]; s_s[i] = v * v; }
     __syncthreads();
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;          // 16 slices of the ci range per output column
     const int co = blockIdx.x * 64 + col;
@@ -111,11 +115,13 @@ extern "C" int ide3d_style_demod(const float* w, int64_t w_stride, const float* 
     IDE3D_CHECK_ARG(w && affine_w && styles, "style_demod: null pointer");
     IDE3D_CHECK_ARG(dcoefs == nullptr || wsq_t != nullptr, "style_demod: dcoefs needs wsq_t");
     IDE3D_CHECK_ARG(n > 0 && cin > 0 && wdim > 0 && (dcoefs == nullptr || cout > 0), "style_demod: bad shape");
-    const size_t lds = ((size_t)wdim + cin + 1024) * sizeof(float);
-    IDE3D_CHECK_ARG(lds <= 60 * 1024, "style_demod: w_dim + cin too large for LDS staging");
-    const int gx = dcoefs ? cdiv(cout, 64) : 1;
-    hipLaunchKernelGGL(style_demod_kernel, dim3(gx, n), dim3(1024), lds, (hipStream_t)stream,
-                       w, w_stride, affine_w, affine_b, wsq_t, n, cin, cout, wdim, affine_gain, bias_gain, styles, dcoefs);
+    IDE3D_CHECK_ARG((size_t)wdim * sizeof(float) <= 60 * 1024 && ((size_t)cin + 1024) * sizeof(float) <= 60 * 1024,
+                    "style_demod: w_dim / cin too large for LDS staging");
+    hipLaunchKernelGGL(style_affine_kernel, dim3(cdiv(cin, STYLE_ROWS), n), dim3(512), (size_t)wdim * sizeof(float), (hipStream_t)stream,
+                       w, w_stride, affine_w, affine_b, cin, wdim, affine_gain, bias_gain, styles);
+    if (dcoefs)
+        hipLaunchKernelGGL(style_demod_kernel, dim3(cdiv(cout, 64), n), dim3(1024), ((size_t)cin + 1024) * sizeof(float), (hipStream_t)stream,
+                           styles, wsq_t, cin, cout, dcoefs);
     IDE3D_CHECK_LAUNCH("style_demod");
     return IDE3D_OK;
 }
