@@ -60,8 +60,9 @@ def conv_flops(spec, n_images):
     return fl * n_images
 
 
-def bench_gather(device, iters=20):
-    """Isolated `sample_from_triplane` at the benchmark shape (N=4 images, channels_last planes): HIP events."""
+def bench_gather(device, iters=20, tiled=True):
+    """Isolated `sample_from_triplane` at the benchmark shape (N=4 images, channels_last planes): HIP events.
+    tiled=True passes the ray-grid hint the renderer has (LDS-staged kernel); False times the flat kernel."""
     from dnnlib import util
     g = torch.Generator().manual_seed(0)
     n, C, H, M = BATCH, 32, 256, 64 * 64 * 96
@@ -72,14 +73,15 @@ def bench_gather(device, iters=20):
     cam = torch.cat([triplane.camera_label(y, device=device) for y in (-0.5, -0.15, 0.2, 0.5)])[:, :16].reshape(-1, 4, 4)
     wp, *_ = vr.transform_sampled_points(pts, z, d, device, h_stddev=0, v_stddev=0, camera=cam, mode=None,
                                          jitter=torch.rand(z.shape, generator=g).to(device))
-    coords = wp.reshape(n, M, 3).contiguous()
+    coords = (wp.reshape(n, M, 3) * float(os.environ.get('IDE3D_BENCH_COORD_SCALE', '1'))).contiguous()   # experiment knob
     del pts, z, d, wp
+    ray_grid = (64, 64, 96) if tiled else None
     for _ in range(3):
-        util.sample_from_triplane(coords, planes)
+        util.sample_from_triplane(coords, planes, ray_grid=ray_grid)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in evs:
-        a.record(); util.sample_from_triplane(coords, planes); b.record()
+        a.record(); util.sample_from_triplane(coords, planes, ray_grid=ray_grid); b.record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     avg = sum(ms) / len(ms)
@@ -87,10 +89,10 @@ def bench_gather(device, iters=20):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
     # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'gather_pmc.json')
+    pmc = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
     if os.path.isfile(pmc):
         traffic = json.load(open(pmc)).get('hbm_traffic_bytes_per_launch')
-    return dict(kernel='triplane_sample_cl2_kernel', bound='hbm', achieved=algo / (avg * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+    return dict(kernel='triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel', bound='hbm', achieved=algo / (avg * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
                 frac=algo / (avg * 1e-3) / HBM_PEAK, traffic=traffic, bytes_per_launch=algo, avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 

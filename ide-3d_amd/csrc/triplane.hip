@@ -354,6 +354,31 @@ extern "C" int ide3d_triplane_sample(const float* planes, const int64_t plane_st
     return IDE3D_OK;
 }
 
+namespace ide3d {
+bool launch_triplane_tile(const float* planes, const int64_t* s, int n, int C, int H, int W, const float* coords, int64_t m,
+                          float* out, int rays_h, int rays_w, int steps, hipStream_t st);   // triplane_tile.hip
+}
+
+extern "C" int ide3d_triplane_sample_rays(const float* planes, const int64_t plane_stride[4],
+                                          int32_t n, int32_t C, int32_t H, int32_t W,
+                                          const float* coords, int64_t m, float* out,
+                                          int32_t rays_h, int32_t rays_w, int32_t steps, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(planes && coords && out && plane_stride, "triplane_sample_rays: null pointer");
+    IDE3D_CHECK_ARG(n > 0 && C > 0 && H > 0 && W > 0 && m >= 0, "triplane_sample_rays: bad shape");
+    IDE3D_CHECK_ARG(rays_h > 0 && rays_w > 0 && steps > 0 && (int64_t)rays_h * rays_w * steps == m,
+                    "triplane_sample_rays: m must equal rays_h * rays_w * steps");
+    static const bool no_tile = getenv("IDE3D_GATHER_NO_TILE") != nullptr;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(planes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                         (plane_stride[0] % 4 == 0) && (plane_stride[2] % 4 == 0) && (plane_stride[3] % 4 == 0);
+    if (!no_tile && aligned &&
+        launch_triplane_tile(planes, plane_stride, n, C, H, W, coords, m, out, rays_h, rays_w, steps, (hipStream_t)stream)) {
+        IDE3D_CHECK_LAUNCH("triplane_sample_rays");
+        return IDE3D_OK;
+    }
+    return ide3d_triplane_sample(planes, plane_stride, n, C, H, W, coords, m, out, stream);
+}
+
 extern "C" int ide3d_triplane_taps(int32_t H, int32_t W, const float* coords, int64_t rows,
                                    int32_t* taps, void* stream) {
     using namespace ide3d;

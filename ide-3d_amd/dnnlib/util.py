@@ -94,11 +94,11 @@ class _TriplaneSampleHip(torch.autograd.Function):
     """HIP tri-plane gather with gradients w.r.t. planes and coordinates."""
 
     @staticmethod
-    def forward(ctx, coordinates, grid):
+    def forward(ctx, coordinates, grid, ray_grid=None):
         if grid.stride(1) != 1:
             # NCHW planes: one channels_last copy so that every bilinear tap is a contiguous C*4-byte read.
             grid = grid.contiguous(memory_format=torch.channels_last)
-        out = _triplane_plugin.sample(grid, coordinates)
+        out = _triplane_plugin.sample(grid, coordinates, ray_grid=ray_grid)
         ctx.save_for_backward(coordinates, grid)
         return out
 
@@ -106,7 +106,7 @@ class _TriplaneSampleHip(torch.autograd.Function):
     def backward(ctx, grad_out):
         coordinates, grid = ctx.saved_tensors
         grad_planes, grad_coords = _triplane_plugin.sample_backward(grad_out, grid, coordinates, ctx.needs_input_grad[0])
-        return (grad_coords if ctx.needs_input_grad[0] else None), (grad_planes if ctx.needs_input_grad[1] else None)
+        return (grad_coords if ctx.needs_input_grad[0] else None), (grad_planes if ctx.needs_input_grad[1] else None), None
 
 
 def sample_from_3dgrid(coordinates, grid):
@@ -138,15 +138,18 @@ def _sample_from_triplane_ref(coordinates, grid):
     return xy + yz + xz
 
 
-def sample_from_triplane(coordinates, grid, impl='cuda'):
+def sample_from_triplane(coordinates, grid, impl='cuda', ray_grid=None):
     """Sum of the xy / yz / xz plane look-ups: coordinates [B, M, 3], grid [B, 3*C, H, W] -> [B*M, C]
-    (reference util.py:580-599; planes are square in every caller)."""
+    (reference util.py:580-599; planes are square in every caller).
+
+    `ray_grid=(rays_h, rays_w, steps)` (ours, optional): the M samples are a flattened [rays_h, rays_w, steps] ray grid, as
+    produced by `transform_sampled_points`; lets the HIP library stage shared texels in LDS.  Results do not depend on it."""
     assert impl in ['ref', 'cuda']
     use_hip = (impl == 'cuda' and grid.device.type == 'cuda' and grid.dtype == torch.float32
                and coordinates.dtype == torch.float32 and grid.shape[2] == grid.shape[3]
                and not grid_sample_gradfix.enabled)
     if use_hip and _triplane_init():
-        return _TriplaneSampleHip.apply(coordinates, grid)
+        return _TriplaneSampleHip.apply(coordinates, grid, ray_grid)
     return _sample_from_triplane_ref(coordinates, grid)
 
 

@@ -165,6 +165,7 @@ def load():
             'ide3d_filtered_lrelu_act': [vp, vp, ctypes.c_int, i32, i32, i32, i32, ctypes.POINTER(i64 * 4),
                                          i32, i32, i32, i32, f32, f32, f32, ctypes.c_int, vp],
             'ide3d_triplane_sample': [vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, i64, vp, vp],
+            'ide3d_triplane_sample_rays': [vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, i64, vp, i32, i32, i32, vp],
             'ide3d_triplane_taps': [i32, i32, vp, i64, vp, vp],
             'ide3d_triplane_sample_backward': [vp, vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, i64,
                                                vp, ctypes.POINTER(i64 * 4), vp, vp],
@@ -188,7 +189,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
-    'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_taps',
+    'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
 )
@@ -442,8 +443,11 @@ class FilteredLReluPlugin:
 
 class TriplanePlugin:
     @staticmethod
-    def sample(planes, coords):
-        """planes [n, 3C, H, W] float32 (any strides), coords [n, m, 3] float32 -> [n*m, C]."""
+    def sample(planes, coords, ray_grid=None):
+        """planes [n, 3C, H, W] float32 (any strides), coords [n, m, 3] float32 -> [n*m, C].
+
+        ray_grid = (rays_h, rays_w, steps) tells the library that coords is [n, rays_h, rays_w, steps, 3] flattened (what
+        the ray-marcher produces): a grouping hint for the LDS-staged kernel, results do not depend on it."""
         _require(planes.is_cuda and coords.device == planes.device, 'planes and coords must be on the same CUDA device')
         _require(planes.dtype == torch.float32 and coords.dtype == torch.float32, 'planes and coords must be float32')
         _require(planes.ndim == 4 and planes.shape[1] % 3 == 0, 'planes must be [n, 3*C, H, W]')
@@ -454,6 +458,14 @@ class TriplanePlugin:
         m = coords.shape[1]
         out = torch.empty([n * m, C], dtype=torch.float32, device=planes.device)
         if m == 0:
+            return out
+        if ray_grid is not None:
+            rh, rw, steps = (int(v) for v in ray_grid)
+            _require(rh * rw * steps == m, 'ray_grid does not match the number of samples')
+            with torch.cuda.device(planes.device):
+                rc = load().ide3d_triplane_sample_rays(_ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
+                                                       _ptr(coords), m, _ptr(out), rh, rw, steps, _stream(planes))
+            _check(rc, 'triplane_sample_rays')
             return out
         with torch.cuda.device(planes.device):
             rc = load().ide3d_triplane_sample(_ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,

@@ -139,17 +139,18 @@ class TriplaneRenderer(torch.nn.Module):
         self.decoder = TriplaneDecoder(spec.plane_channels, spec.decoder_hidden, spec.feature_channels, spec.seg_channels)
 
     # -- point queries ---------------------------------------------------------------------------------
-    def sample_voxel(self, img_v, seg_v, pts, sigma_only=False):
+    def sample_voxel(self, img_v, seg_v, pts, sigma_only=False, ray_grid=None):
         """Features at world points.  img_v / seg_v [B, 3C, H, W], pts [B, M, 3] -> [B*M, feat + seg + 1]
-        (sigma last; extract_shapes.py:146).  `sigma_only=True` returns [B*M] densities."""
+        (sigma last; extract_shapes.py:146).  `sigma_only=True` returns [B*M] densities.  `ray_grid=(H, W, steps)` tells the
+        step-wise gather that pts is a flattened ray grid (see dnnlib.util.sample_from_triplane)."""
         if self._hip_ok(img_v, seg_v, pts):
             vr._init()
             tex, geo = _as_channels_last(img_v), _as_channels_last(seg_v)
             out = vr._plugin.sample_voxel(tex, geo, self.decoder.kernel_weights(), pts.float(), sigma_only=sigma_only)
             if out is not None:
                 return out
-        geo_feat = util.sample_from_triplane(pts, seg_v)
-        tex_feat = util.sample_from_triplane(pts, img_v)
+        geo_feat = util.sample_from_triplane(pts, seg_v, ray_grid=ray_grid)
+        tex_feat = util.sample_from_triplane(pts, img_v, ray_grid=ray_grid)
         out = self.decoder(tex_feat, geo_feat)
         return out[:, -1] if sigma_only else out
 
@@ -195,7 +196,7 @@ class TriplaneRenderer(torch.nn.Module):
         pts, z_vals, _rd, _ro, _p, _y = vr.transform_sampled_points(
             points, z_vals, rays_d_cam, device, h_stddev=0, v_stddev=0, camera=cam2world, mode=None,
             jitter=(jitter.unsqueeze(-1) if jitter is not None else torch.full_like(z_vals, 0.5)))
-        out = self.sample_voxel(img_v, seg_v, pts.reshape(n, -1, 3)).reshape(n, rays, steps, -1)
+        out = self.sample_voxel(img_v, seg_v, pts.reshape(n, -1, 3), ray_grid=(size, size, steps)).reshape(n, rays, steps, -1)
         noise = sigma_noise.unsqueeze(-1) if sigma_noise is not None else None
         feat, depth, weights = vr.fancy_integration(out, rays_d_cam, z_vals, device, noise_std=(1.0 if noise is not None else 0.0),
                                                     white_back=white_back, clamp_mode=clamp_mode, noise=noise)

@@ -178,6 +178,19 @@ int ide3d_triplane_sample(const float* planes, const int64_t plane_stride[4],
                           const float* coords, int64_t m, float* out, void* stream);
 
 /*
+ * Same operation and same results, for samples that come from a ray grid (what the ray-marcher
+ * of volumetric_rendering.py:160-191 produces): coords is [n, rays_h, rays_w, steps, 3], i.e.
+ * m == rays_h * rays_w * steps with the depth step innermost.  The shape is a grouping hint
+ * only: 8x8 ray tiles x 4 depth steps stage the plane texels they share in LDS once instead of
+ * fetching them per sample.  Any coordinates are legal; shapes / layouts the tiled kernel does
+ * not cover run `ide3d_triplane_sample`.
+ */
+int ide3d_triplane_sample_rays(const float* planes, const int64_t plane_stride[4],
+                               int32_t n, int32_t C, int32_t H, int32_t W,
+                               const float* coords, int64_t m, float* out,
+                               int32_t rays_h, int32_t rays_w, int32_t steps, void* stream);
+
+/*
  * Debug / parity hook: writes, per sample and plane, the integer tap origin (floor(u),
  * floor(v)) and the in-bounds mask of the four taps, so tests can assert bit-exact index
  * math against the oracle.  taps: int32 [n*m, 3, 3] = (ix0, iy0, mask4).

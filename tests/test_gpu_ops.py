@@ -257,6 +257,43 @@ def test_triplane_full_size_properties(gpu_device):
     assert_close(o1[idx], ref, rtol=1e-5, atol=2e-5, what='subset vs oracle')
 
 
+def test_triplane_ray_grid_kernel_equals_flat_kernel(gpu_device):
+    """`ide3d_triplane_sample_rays` (LDS-staged 8x8-ray tiles) == `ide3d_triplane_sample`, bit for bit: frustum coordinates
+    (regions staged), uniformly random and wild coordinates (regions too large / out of the plane -> direct loads), ray
+    grids the tile kernel does not cover (falls back to the flat kernel), and vs the oracle on a subset."""
+    from dnnlib import util
+    from training import triplane, volumetric_rendering as vr
+    g = torch.Generator().manual_seed(21)
+    n, C, H = 3, 32, 256
+    planes = torch.randn(n, 3 * C, H, H, generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last)
+
+    def frustum(res, steps, yaws, pitch=math.pi / 2):
+        pts, z, d = vr.get_initial_rays_trig(len(yaws), steps, gpu_device, 18.0, res, 2.25, 3.3)
+        cam = torch.cat([triplane.camera_label(y, pitch=pitch, device=gpu_device) for y in yaws])[:, :16].reshape(-1, 4, 4)
+        wp, *_ = vr.transform_sampled_points(pts, z, d, gpu_device, h_stddev=0, v_stddev=0, camera=cam, mode=None,
+                                             jitter=torch.rand(z.shape, generator=g).to(gpu_device))
+        return wp.reshape(len(yaws), -1, 3).contiguous()
+
+    cases = []
+    cases.append(('frustum 64x64x96', frustum((64, 64), 96, (-0.6, 0.0, 0.45)), (64, 64, 96)))
+    cases.append(('frustum 16x24x12 pitched', frustum((16, 24), 12, (1.2, -1.5, 3.0), pitch=1.1), (16, 24, 12)))
+    cases.append(('frustum x2.6 (leaves the planes)', frustum((32, 32), 48, (0.3, 0.9, -2.0)) * 2.6, (32, 32, 48)))
+    rnd = (torch.rand(n, 16 * 16 * 8, 3, generator=g) * 2 - 1) * 1.1
+    rnd[0, :6] = torch.tensor([[float('nan'), 0, 0], [float('inf'), 0.1, 0], [1e30, -1e30, 0], [1, -1, 1], [-1, 1, -1], [0.999999, 0, -0.999999]])
+    cases.append(('random + wild', rnd.to(gpu_device), (16, 16, 8)))
+    cases.append(('grid not covered by the tile kernel', frustum((12, 20), 10, (0.1, 0.2, 0.3)), (12, 20, 10)))
+    for name, co, rg in cases:
+        flat = util.sample_from_triplane(co, planes)
+        tiled = util.sample_from_triplane(co, planes, ray_grid=rg)
+        assert torch.equal(torch.nan_to_num(flat, nan=123.0), torch.nan_to_num(tiled, nan=123.0)), name
+    assert _calls('triplane_sample_rays') == len(cases)
+    co = cases[0][1]
+    idx = torch.arange(0, co.shape[1], 1009, device=gpu_device)
+    ref = fast_ops.sample_from_triplane(co[:, idx].cpu(), planes.cpu().contiguous())
+    got = util.sample_from_triplane(co, planes, ray_grid=(64, 64, 96)).reshape(n, -1, C)[:, idx].reshape(-1, C)
+    assert_close(got, ref, rtol=1e-5, atol=2e-5, what='tiled vs oracle')
+
+
 def test_triplane_backward(gpu_device):
     from dnnlib import util
     g = torch.Generator().manual_seed(10)
