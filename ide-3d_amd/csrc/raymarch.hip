@@ -271,10 +271,44 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     }
 }
 
+// Where sample_voxel takes its points from: an [n, m, 3] array, or the extract_shapes.py lattice generated in registers.
+struct PointsFromMemory {
+    const float* pts;
+    __device__ __forceinline__ void get(int64_t row, int64_t /*m*/, float& x, float& y, float& z) const {
+        x = pts[row * 3 + 0]; y = pts[row * 3 + 1]; z = pts[row * 3 + 2];
+    }
+};
+
+// extract_shapes.py:74-96 + the 0.9 scale of :103, evaluated like the reference's fp32 tensor ops, one rounding each:
+// i -> float, column 2 = i % N, column 1 = (i / N) % N, column 0 = ((i / N) / N) % N with *float* division (the
+// reference does not floor: its y / x "indices" carry a fractional part), then (v * voxel_size + corner) * scale.
+struct PointsFromLattice {
+    ide3d_lattice lat;
+    int64_t first;
+    __device__ __forceinline__ void get(int64_t row, int64_t m, float& x, float& y, float& z) const {
+        const int64_t i = first + row % m;
+        const float fn = (float)lat.n, fi = (float)i;                       // int64 -> fp32, round to nearest even
+        const float q = __fdiv_rn(fi, fn);
+        const float s2 = (float)(i % lat.n), s1 = fmodf(q, fn), s0 = fmodf(__fdiv_rn(q, fn), fn);
+        x = __fmul_rn(__fadd_rn(__fmul_rn(s0, lat.voxel_size), lat.corner[2]), lat.scale);
+        y = __fmul_rn(__fadd_rn(__fmul_rn(s1, lat.voxel_size), lat.corner[1]), lat.scale);
+        z = __fmul_rn(__fadd_rn(__fmul_rn(s2, lat.voxel_size), lat.corner[0]), lat.scale);
+    }
+};
+
+template <class Src>
+__global__ void lattice_points_kernel(Src src, int64_t count, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float x, y, z;
+        src.get(i, count, x, y, z);
+        out[i * 3 + 0] = x; out[i * 3 + 1] = y; out[i * 3 + 2] = z;
+    }
+}
+
 // sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
-template <int C, int HID>
+template <int C, int HID, class Src>
 __global__ void __launch_bounds__(256, 2)
-sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_t m,
+sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
                     float* __restrict__ out, float* __restrict__ out_sigma, int sigma_only, int64_t tiles_per_block) {
     using K = RmCfg<C, HID>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -301,7 +335,8 @@ sample_voxel_kernel(ide3d_render_params p, const float* __restrict__ pts, int64_
         const bool live = row < rows;
         const int64_t rc = live ? row : rows - 1;
         const int n = (int)(rc / m);
-        const float wx = pts[rc * 3 + 0], wy = pts[rc * 3 + 1], wz = pts[rc * 3 + 2];
+        float wx, wy, wz;
+        src.get(rc, m, wx, wy, wz);
         const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
                                make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
         float fg[K::NF];
@@ -352,8 +387,8 @@ static int launch_render(const ide3d_render_params& p, hipStream_t st) {
     return IDE3D_OK;
 }
 
-template <int C, int HID>
-static int launch_voxel(const ide3d_render_params& p, const float* pts, int64_t m, float* out, float* out_sigma,
+template <int C, int HID, class Src>
+static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m, float* out, float* out_sigma,
                         int sigma_only, hipStream_t st) {
     using K = RmCfg<C, HID>;
     const int width = p.feat_ch + p.seg_ch + 1;
@@ -363,9 +398,9 @@ static int launch_voxel(const ide3d_render_params& p, const float* pts, int64_t 
     int64_t tpb = cdiv64(cdiv64(ntiles, nblk), 4) * 4;
     if (tpb < 4) tpb = 4;
     nblk = cdiv64(ntiles, tpb);
-    auto kern = sample_voxel_kernel<C, HID>;
+    auto kern = sample_voxel_kernel<C, HID, Src>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, pts, m, out, out_sigma, sigma_only, tpb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out, out_sigma, sigma_only, tpb);
     IDE3D_CHECK_LAUNCH("sample_voxel");
     return IDE3D_OK;
 }
@@ -424,8 +459,50 @@ extern "C" int ide3d_sample_voxel(const ide3d_render_params* pp, const float* pt
     if (m == 0) return IDE3D_OK;
     if (!planes_fast(p)) { set_error("sample_voxel: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
-    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, pts, m, out, out_sigma, sigma_only, st);
-    if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, pts, m, out, out_sigma, sigma_only, st);
+    const PointsFromMemory src{pts};
+    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, src, m, out, out_sigma, sigma_only, st);
+    if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, src, m, out, out_sigma, sigma_only, st);
     set_error("sample_voxel: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
+    return IDE3D_ENOKERNEL;
+}
+
+static int check_lattice(const ide3d_lattice* lat, int64_t first, int64_t count, const char* what) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(lat != nullptr && lat->n >= 2 && lat->n <= 2048, "%s: lattice resolution must be in [2, 2048]", what);
+    const int64_t total = (int64_t)lat->n * lat->n * lat->n;
+    IDE3D_CHECK_ARG(first >= 0 && count >= 0 && first + count <= total, "%s: point range outside the lattice", what);
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_lattice_points(const ide3d_lattice* lat, int64_t first, int64_t count, float* pts, void* stream) {
+    using namespace ide3d;
+    int rc = check_lattice(lat, first, count, "lattice_points");
+    if (rc) return rc;
+    IDE3D_CHECK_ARG(pts != nullptr || count == 0, "lattice_points: null output");
+    if (count == 0) return IDE3D_OK;
+    const PointsFromLattice src{*lat, first};
+    hipLaunchKernelGGL(lattice_points_kernel<PointsFromLattice>, dim3(stream_grid(count, 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, count, pts);
+    IDE3D_CHECK_LAUNCH("lattice_points");
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_density_lattice(const ide3d_render_params* pp, const ide3d_lattice* lat, int64_t first, int64_t count,
+                                     float* out_sigma, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(pp != nullptr, "density_lattice: null params");
+    const ide3d_render_params& p = *pp;
+    int rc = check_render_params(p, "density_lattice", false);
+    if (rc) return rc;
+    rc = check_lattice(lat, first, count, "density_lattice");
+    if (rc) return rc;
+    IDE3D_CHECK_ARG(out_sigma != nullptr || count == 0, "density_lattice: null output");
+    if (count == 0) return IDE3D_OK;
+    if (!planes_fast(p)) { set_error("density_lattice: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
+    hipStream_t st = (hipStream_t)stream;
+    const PointsFromLattice src{*lat, first};
+    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, src, count, nullptr, out_sigma, 1, st);
+    if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, src, count, nullptr, out_sigma, 1, st);
+    set_error("density_lattice: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
     return IDE3D_ENOKERNEL;
 }

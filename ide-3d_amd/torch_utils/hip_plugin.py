@@ -83,6 +83,10 @@ class _FlreluParams(ctypes.Structure):
     ]
 
 
+class _Lattice(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int32), ('voxel_size', ctypes.c_float), ('corner', ctypes.c_float * 3), ('scale', ctypes.c_float)]
+
+
 class _RenderParams(ctypes.Structure):
     _fields_ = [
         ('rays_d_cam', ctypes.c_void_p), ('z_lin', ctypes.c_void_p), ('cam2world', ctypes.c_void_p),
@@ -173,6 +177,8 @@ def load():
                                 ctypes.c_int, vp, vp, vp, vp],
             'ide3d_render_rays': [ctypes.POINTER(_RenderParams), vp],
             'ide3d_sample_voxel': [ctypes.POINTER(_RenderParams), vp, i64, vp, vp, ctypes.c_int, vp],
+            'ide3d_lattice_points': [ctypes.POINTER(_Lattice), i64, i64, vp, vp],
+            'ide3d_density_lattice': [ctypes.POINTER(_RenderParams), ctypes.POINTER(_Lattice), i64, i64, vp, vp],
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
             'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32, i32],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
@@ -191,6 +197,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
+    'ide3d_lattice_points', 'ide3d_density_lattice',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
 )
 
@@ -590,6 +597,42 @@ class VolumeRenderPlugin:
                 return None
             _check(rc, 'sample_voxel')
         return sig if sigma_only else out
+
+
+    @staticmethod
+    def _lattice(n, voxel_size, corner, scale):
+        lat = _Lattice()
+        lat.n, lat.voxel_size, lat.scale = int(n), float(voxel_size), float(scale)
+        for i in range(3):
+            lat.corner[i] = float(corner[i])
+        return lat
+
+    @staticmethod
+    def lattice_points(n, voxel_size, corner, scale, first, count, device):
+        """Points [first, first + count) of the extract_shapes lattice (see ide3d_lattice in the header) -> [count, 3]."""
+        device = torch.device(device)
+        _require(device.type == 'cuda', 'lattice_points: CUDA device required')
+        pts = torch.empty([count, 3], dtype=torch.float32, device=device)
+        lat = VolumeRenderPlugin._lattice(n, voxel_size, corner, scale)
+        with torch.cuda.device(device):
+            rc = load().ide3d_lattice_points(ctypes.byref(lat), int(first), int(count), _ptr(pts), _stream(pts))
+        _check(rc, 'lattice_points')
+        return pts
+
+    @staticmethod
+    def density_lattice(tex_planes, geo_planes, mlp, n, voxel_size, corner, scale, first, count):
+        """sigma of lattice points [first, first + count) for every image -> [batch * count]; None if no fused kernel."""
+        p = _RenderParams()
+        VolumeRenderPlugin._fill_render_params(p, tex_planes, geo_planes, mlp)
+        lat = VolumeRenderPlugin._lattice(n, voxel_size, corner, scale)
+        sig = torch.empty([p.n * int(count)], dtype=torch.float32, device=tex_planes.device)
+        if count:
+            with torch.cuda.device(tex_planes.device):
+                rc = load().ide3d_density_lattice(ctypes.byref(p), ctypes.byref(lat), int(first), int(count), _ptr(sig), _stream(tex_planes))
+            if rc == -2:
+                return None
+            _check(rc, 'density_lattice')
+        return sig
 
 
 class ModconvPlugin:

@@ -154,6 +154,19 @@ class TriplaneRenderer(torch.nn.Module):
         out = self.decoder(tex_feat, geo_feat)
         return out[:, -1] if sigma_only else out
 
+    def density_lattice(self, img_v, seg_v, n, voxel_size, corner, scale, first, count):
+        """Densities of points [first, first+count) of the extract_shapes.py lattice (training.shape_extraction) -> [B*count].
+        On the GPU the points are generated inside the fused kernel; elsewhere they are materialised and queried."""
+        if self._hip_ok(img_v, seg_v):
+            vr._init()
+            out = vr._plugin.density_lattice(_as_channels_last(img_v), _as_channels_last(seg_v), self.decoder.kernel_weights(),
+                                             n, voxel_size, corner, scale, first, count)
+            if out is not None:
+                return out
+        from training import shape_extraction
+        pts = shape_extraction.lattice_points(n, voxel_size, corner, scale, first, count, img_v.device)
+        return self.sample_voxel(img_v, seg_v, pts.unsqueeze(0).expand(img_v.shape[0], -1, -1), sigma_only=True)
+
     @staticmethod
     def _hip_ok(*tensors):
         if any(t.device.type != 'cuda' or t.dtype != torch.float32 for t in tensors):

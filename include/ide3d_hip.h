@@ -276,6 +276,34 @@ int ide3d_render_rays(const ide3d_render_params* p, void* stream);
 int ide3d_sample_voxel(const ide3d_render_params* p, const float* pts, int64_t m,
                        float* out, float* out_sigma, int sigma_only, void* stream);
 
+/*
+ * The point lattice of `extract_shapes.create_samples` (extract_shapes.py:74-96) with the
+ * 0.9 scale of extract_shapes.py:103 folded in: point i (0 <= i < n^3) is
+ *   s2 = i % n,  s1 = (float(i) / n) % n,  s0 = ((float(i) / n) / n) % n     (fp32, NOT floored: reference quirk)
+ *   (x, y, z) = ((s0 * voxel_size + corner[2]) * scale, (s1 * voxel_size + corner[1]) * scale,
+ *                (s2 * voxel_size + corner[0]) * scale)
+ * with every operation rounded to fp32 separately, i.e. bit-equal to the reference's host code.
+ * corner = voxel_origin - cube_length / 2, voxel_size = cube_length / (n - 1), both rounded to fp32.
+ */
+typedef struct ide3d_lattice {
+    int32_t n;
+    float   voxel_size;
+    float   corner[3];
+    float   scale;
+} ide3d_lattice;
+
+/* Writes points [first, first + count) of the lattice to pts [count, 3] (device). */
+int ide3d_lattice_points(const ide3d_lattice* lat, int64_t first, int64_t count, float* pts, void* stream);
+
+/*
+ * The chunk loop body of extract_shapes.py:144-148 without materialising coordinates:
+ * `renderer.sample_voxel(img_v, seg_v, samples[:, first:first+count])[..., -1]` for every image
+ * of p (p->n), lattice points generated in registers.  out_sigma: [p->n * count].
+ * (p's ray / compositing fields are ignored, as in ide3d_sample_voxel.)
+ */
+int ide3d_density_lattice(const ide3d_render_params* p, const ide3d_lattice* lat, int64_t first, int64_t count,
+                          float* out_sigma, void* stream);
+
 /* ---- modulated 3x3 / 1x1 convolution (MFMA implicit GEMM) --------------------------------- */
 /*
  * Replaces the ATen conv behind `conv2d_gradfix.conv2d` for the StyleGAN2 modulated

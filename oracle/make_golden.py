@@ -367,13 +367,20 @@ def gen_post():
     frame = torch.cat([img, (col / 255. - 0.5) / 0.5], dim=-1)
     u8 = r_util.layout_grid(frame, grid_w=2, grid_h=1, to_numpy=False)        # [H, 2*(2W), 3]
     samples, _, _ = ns['create_samples'](N=6, voxel_origin=[0, 0, 0], cube_length=1.0)
+    samples2, origin2, size2 = ns['create_samples'](N=16, voxel_origin=[0.1, -0.2, 0.05], cube_length=2.0)
     cases = [dict(cfg=dict(fn='frame'), in_img=img, in_seg=seg, out_color=col, out_grid_u8=u8),
-             dict(cfg=dict(fn='create_samples', N=6, cube_length=1.0), out_samples=samples)]
+             dict(cfg=dict(fn='create_samples', N=6, cube_length=1.0), out_samples=samples),
+             dict(cfg=dict(fn='create_samples', N=16, cube_length=2.0, voxel_origin=[0.1, -0.2, 0.05], voxel_size=float(size2)),
+                  out_samples=samples2, out_origin=torch.from_numpy(np.asarray(origin2, dtype=np.float64)))]
     save('post', cases)
 
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:                       # regenerate only the named fixtures: python oracle/make_golden.py post ...
+        for name in sys.argv[1:]:
+            globals()['gen_' + name]()
+        sys.exit(0)
     gen_bias_act()
     gen_upfirdn2d()
     gen_filtered_lrelu()

@@ -151,20 +151,36 @@ def test_generator_full_size_vs_oracle(gpu_device):
 
 
 def test_extract_shapes_density_cube(golden, gpu_device):
-    """extract_shapes.py loop (:99-150) on a small lattice: chunked sigma-only queries == oracle."""
+    """extract_shapes.py loop (:99-150) through training.shape_extraction: the device-built lattice is bit-equal to the
+    host-built one, chunked and single-launch sigma-only queries agree, and the cube equals the oracle's."""
+    from training import shape_extraction as se
     G, cfg, a = _load(golden, gpu_device)
+    for N, origin, length in ((12, (0, 0, 0), 1.0), (32, (0.1, -0.2, 0.05), 2.0)):
+        dev, _, _ = se.create_samples(N, origin, length, device=gpu_device)
+        host, _, _ = se.create_samples(N, origin, length)
+        assert torch.equal(dev.cpu(), host)
     N = 12
-    samples = (0.9 * oracle_ops.create_samples(N, cube_length=1.0)).to(gpu_device)
     img_v, seg_v = t(a['out_img_v'], gpu_device)[:1], t(a['out_seg_v'], gpu_device)[:1]
-    sig = torch.zeros(1, N ** 3, device=gpu_device)
+    before, before_sv = _calls('density_lattice'), _calls('sample_voxel')
     with torch.no_grad():
-        head, step = 0, 500
-        while head < N ** 3:
-            sig[:, head:head + step] = G.synthesis.renderer.sample_voxel(img_v, seg_v, samples[:, head:head + step], sigma_only=True).reshape(1, -1)
-            head += step
+        cube = se.density_cube(G.synthesis.renderer, img_v, seg_v, voxel_resolution=N, max_batch=500, cube_length=1.0)
+        one = se.density_cube(G.synthesis.renderer, img_v, seg_v, voxel_resolution=N, max_batch=None, cube_length=1.0)
+        mat = se.density_cube(G.synthesis.renderer, img_v, seg_v, voxel_resolution=N, max_batch=700, cube_length=1.0, materialize=True)
+    assert _calls('density_lattice') - before == math.ceil(N ** 3 / 500) + 1          # points generated in the kernel
+    assert _calls('sample_voxel') - before_sv == math.ceil(N ** 3 / 700)              # reference-style materialised lattice
+    assert cube.shape == (1, N, N, N) and torch.equal(cube, one) and torch.equal(cube, mat)
     sd = {k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')}
-    ref = ogen.sample_voxel(sd, ospec.tiny(), img_v.cpu(), seg_v.cpu(), samples.cpu(), fast_ops)[:, -1]
-    _rel(sig[0], ref, 2e-4, 'sigma lattice')
+    samples = 0.9 * oracle_ops.create_samples(N, cube_length=1.0)
+    ref = ogen.sample_voxel(sd, ospec.tiny(), img_v.cpu(), seg_v.cpu(), samples, fast_ops)[:, -1]
+    _rel(cube.reshape(-1), ref, 2e-4, 'sigma lattice')
+    # whole driver (mapping -> tri-planes -> cube) on the GPU vs on the CPU definitions of the same modules
+    z, c = t(a['in_z'], gpu_device)[:1], t(a['in_c_cond'], gpu_device)[:1]
+    got = se.sample_generator_ide3d(G, None, z, c, max_batch=700, voxel_resolution=N, cube_length=1.0, psi=cfg['truncation_psi'],
+                                    noise_mode='const')
+    ws = ogen.mapping(sd, ospec.tiny(), z.cpu(), c.cpu(), truncation_psi=cfg['truncation_psi'], ops=fast_ops)
+    planes = ogen.backbone(sd, ospec.tiny(), ws, 'const', fast_ops)
+    ref = ogen.sample_voxel(sd, ospec.tiny(), planes[0], planes[1], samples, fast_ops)[:, -1]
+    _rel(torch.from_numpy(got).reshape(-1), ref, 5e-4, 'driver density cube')
 
 
 def test_hipgraph_replay_equals_eager(golden, gpu_device):

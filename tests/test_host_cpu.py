@@ -11,6 +11,10 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import fast_ops
+from oracle import generator as ogen
+from oracle import ops as oracle_ops
+from oracle import spec as ospec
 from util import assert_close, filter_from, t
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +49,8 @@ def test_ctypes_structs_match_header_layout():
     from torch_utils import hip_plugin
     src = open(os.path.join(ROOT, 'include', 'ide3d_hip.h')).read()
     for cname, cls in (('ide3d_upfirdn2d_params', hip_plugin._UpfirdnParams), ('ide3d_filtered_lrelu_params', hip_plugin._FlreluParams),
-                       ('ide3d_render_params', hip_plugin._RenderParams), ('ide3d_modconv_params', hip_plugin._ModconvParams)):
+                       ('ide3d_render_params', hip_plugin._RenderParams), ('ide3d_modconv_params', hip_plugin._ModconvParams),
+                       ('ide3d_lattice', hip_plugin._Lattice)):
         body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, re.S).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []
@@ -204,6 +209,30 @@ def test_generator_matches_reference_assembly_cpu(golden):
     assert_close(sv, a['out_sample_out'], rtol=1e-4, atol=1e-5, what='sample_voxel')
     img, seg = G.synthesis(t(a['out_ws']), c=t(a['in_c']), ray_jitter=t(a['in_jitter']), return_seg=True)
     assert img.shape == (2, 3, 64, 64) and seg.shape == (2, 5, 64, 64)
+
+
+def test_shape_extraction_cpu(golden):
+    """extract_shapes.py lattice (bit-exact vs the reference-run fixture) and chunked density query == oracle (tiny G)."""
+    from training import shape_extraction as se, triplane
+    for cfg, a in golden('post').select(fn='create_samples'):
+        s, origin, size = se.create_samples(cfg['N'], voxel_origin=cfg.get('voxel_origin', (0, 0, 0)), cube_length=cfg['cube_length'])
+        assert np.array_equal(s.numpy(), a['out_samples'])
+        if 'out_origin' in a:
+            assert np.array_equal(origin, a['out_origin']) and size == cfg['voxel_size']
+    (cfg, a), = golden('generator_tiny').cases
+    G = triplane.TriPlaneGenerator(triplane.tiny_spec()).eval()
+    sd = {k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')}
+    G.load_state_dict(sd)
+    z, c = t(a['in_z'])[:1], t(a['in_c_cond'])[:1]
+    N = 10
+    cube = se.sample_generator_ide3d(G, None, z, c, max_batch=300, voxel_resolution=N, cube_length=1.0, psi=cfg['truncation_psi'], noise_mode='const')
+    assert cube.shape == (N, N, N) and cube.dtype == np.float32
+    ws = ogen.mapping(sd, ospec.tiny(), z, c, truncation_psi=cfg['truncation_psi'], ops=fast_ops)
+    planes = ogen.backbone(sd, ospec.tiny(), ws, 'const', fast_ops)
+    ref = ogen.sample_voxel(sd, ospec.tiny(), planes[0], planes[1], 0.9 * oracle_ops.create_samples(N, cube_length=1.0), fast_ops)[:, -1]
+    assert_close(torch.from_numpy(cube).reshape(-1), ref, rtol=1e-4, atol=1e-5, what='density cube')
+    one = se.sample_generator_ide3d(G, None, z, c, max_batch=None, voxel_resolution=N, cube_length=1.0, psi=cfg['truncation_psi'], noise_mode='const')
+    assert np.array_equal(one, cube)
 
 
 def test_full_spec_shapes():
