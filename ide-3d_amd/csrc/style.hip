@@ -10,22 +10,35 @@
 
 namespace ide3d {
 
-// styles[n, :] = w[n, :] @ A^T * a_gain + b * b_gain (* out_scale).  Each wave owns rows i = wave, wave + nwaves, ...
-// and keeps RB rows' loads in flight at once (the dot products are latency-, not bandwidth-bound).
+// styles[n, :] = w[n, :] @ A^T * a_gain + b * b_gain (* out_scale).  Each wave owns rows i = wave*RB .. wave*RB + RB-1,
+// then + nwaves*RB, ...  The dot products are latency-, not bandwidth-bound (the weights come from HBM / the infinity
+// cache, ~2 us per dependent round trip), so a wave requests all RB rows of a 256-column slab as 16-byte loads before
+// it touches any of them: RB loads in flight per lane, wdim / 256 round trips per row group.
+template <int RB>
 __device__ __forceinline__ void affine_rows(const float* __restrict__ wv, const float* __restrict__ A, const float* __restrict__ b,
                                             int cin, int wdim, float a_gain, float b_gain, float out_scale, float* __restrict__ s_out) {
-    constexpr int RB = 8;
     const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const bool vec = (wdim % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     for (int i0 = wid * RB; i0 < cin; i0 += nw * RB) {
         float acc[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-        for (int k = lane; k < wdim; k += kWave) {
-            const float wk = wv[k];
+        if (vec) {
+#pragma unroll 2
+            for (int k = lane * 4; k < wdim; k += kWave * 4) {
+                float4 a[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int i = min(i0 + r, cin - 1);
-                acc[r] += A[(int64_t)i * wdim + k] * wk;
+                for (int r = 0; r < RB; ++r)
+                    a[r] = *reinterpret_cast<const float4*>(A + (int64_t)min(i0 + r, cin - 1) * wdim + k);
+                const float4 wk = *reinterpret_cast<const float4*>(wv + k);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] += (a[r].x * wk.x + a[r].y * wk.y) + (a[r].z * wk.z + a[r].w * wk.w);
+            }
+        } else {
+            for (int k = lane; k < wdim; k += kWave) {
+                const float wk = wv[k];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] += A[(int64_t)min(i0 + r, cin - 1) * wdim + k] * wk;
             }
         }
 #pragma unroll
@@ -38,10 +51,49 @@ __device__ __forceinline__ void affine_rows(const float* __restrict__ wv, const 
     }
 }
 
-// phase A, grid (ceil(cin / STYLE_ROWS), n): styles[n, rows of this block].
-constexpr int STYLE_ROWS = 64;
+// Same, run by one half (8 waves) of a 16-wave workgroup: rows wave%8 * 8 ...
+template <int HALF>
+__device__ __forceinline__ void affine_rows_half(const float* __restrict__ wv, const float* __restrict__ A, const float* __restrict__ b,
+                                                 int cin, int wdim, float a_gain, float out_scale, float* __restrict__ s_out) {
+    constexpr int RB = 8;
+    const int lane = lane_id(), wid = (threadIdx.x >> 6) - HALF * 8;
+    const bool vec = (wdim % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    for (int i0 = wid * RB; i0 < cin; i0 += 8 * RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        if (vec) {
+#pragma unroll 2
+            for (int k = lane * 4; k < wdim; k += kWave * 4) {
+                float4 a[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    a[r] = *reinterpret_cast<const float4*>(A + (int64_t)min(i0 + r, cin - 1) * wdim + k);
+                const float4 wk = *reinterpret_cast<const float4*>(wv + k);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] += (a[r].x * wk.x + a[r].y * wk.y) + (a[r].z * wk.z + a[r].w * wk.w);
+            }
+        } else {
+            for (int k = lane; k < wdim; k += kWave) {
+                const float wk = wv[k];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] += A[(int64_t)min(i0 + r, cin - 1) * wdim + k] * wk;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off);
+            const int i = i0 + r;
+            if (lane == 0 && i < cin) s_out[i] = (acc[r] * a_gain + (b ? b[i] : 0.f)) * out_scale;
+        }
+    }
+}
 
-__global__ void __launch_bounds__(512)
+// phase A, grid (ceil(cin / STYLE_ROWS), n): styles[n, rows of this block].
+constexpr int STYLE_ROWS = 32;           // 4 waves x 8 rows: cin / 32 x n workgroups (64 for cin = 512, n = 4)
+
+__global__ void __launch_bounds__(256)
 style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
                     int cin, int wdim, float a_gain, float b_gain, float* __restrict__ styles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -50,30 +102,55 @@ style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* 
     const int rows = min(STYLE_ROWS, cin - i0);
     for (int k = threadIdx.x; k < wdim; k += blockDim.x) s_w[k] = w[(int64_t)img * w_stride + k];
     __syncthreads();
-    affine_rows(s_w, A + (int64_t)i0 * wdim, b ? b + i0 : nullptr, rows, wdim, a_gain, b_gain, 1.0f, styles + (int64_t)img * cin + i0);
+    affine_rows<8>(s_w, A + (int64_t)i0 * wdim, b ? b + i0 : nullptr, rows, wdim, a_gain, b_gain, 1.0f, styles + (int64_t)img * cin + i0);
 }
 
-// phase B, grid (ceil(cout / 64), n): dcoefs[n, o] = rsqrt(sum_i styles[n, i]^2 * wsq_t[i, o] + 1e-8); wsq_t [cin, cout].
+// phase B, grid ceil(cout / 32): dcoefs[img, o] = rsqrt(sum_i styles[img, i]^2 * wsq_t[i, o] + 1e-8) for every image; wsq_t
+// [cin, cout].  A workgroup owns 32 output columns: thread = (column, one of 32 interleaved slices of the ci range); a
+// thread requests its whole slice of wsq_t (up to DEMOD_MAX_CI / 32 values) before using any, and every value serves
+// all images (wsq_t is read once, not once per image).
+constexpr int DEMOD_COLS = 32, DEMOD_PARTS = 32, DEMOD_MAX_CI = 512, DEMOD_MAX_N = 8;
+
 __global__ void __launch_bounds__(1024)
-style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq_t, int cin, int cout, float* __restrict__ dcoefs) {
+style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq_t, int n, int cin, int cout, float* __restrict__ dcoefs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_s = lds;                 // [cin] squared styles
-    float* s_p = lds + cin;           // [16][64] partial sums
-    const int img = blockIdx.y;
-    for (int i = threadIdx.x; i < cin; i += blockDim.x) { const float v = styles[(int64_t)img * cin + i]; s_s[i] = v * v; }
+    float* s_s = lds;                                   // [n][cin] squared styles
+    float* s_p = lds + (size_t)n * cin;                 // [DEMOD_PARTS][DEMOD_COLS] partial sums of one image
+    for (int i = threadIdx.x; i < n * cin; i += blockDim.x) { const float v = styles[i]; s_s[i] = v * v; }
     __syncthreads();
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;          // 16 slices of the ci range per output column
-    const int co = blockIdx.x * 64 + col;
-    float acc = 0.f;
-    if (co < cout)
-        for (int i = part; i < cin; i += 16) acc += s_s[i] * wsq_t[(int64_t)i * cout + co];
-    s_p[part * 64 + col] = acc;
-    __syncthreads();
-    if (part == 0 && co < cout) {
-        float t = 0.f;
+    const int col = threadIdx.x & (DEMOD_COLS - 1), part = threadIdx.x / DEMOD_COLS;
+    const int co = blockIdx.x * DEMOD_COLS + col, coc = min(co, cout - 1);
+    float acc[DEMOD_MAX_N];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += s_p[q * 64 + col];
-        dcoefs[(int64_t)img * cout + co] = rsqrtf(t + 1e-8f);
+    for (int g = 0; g < DEMOD_MAX_N; ++g) acc[g] = 0.f;
+    for (int c0 = 0; c0 < cin; c0 += DEMOD_MAX_CI) {
+        constexpr int PER = DEMOD_MAX_CI / DEMOD_PARTS;
+        float v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = c0 + part + q * DEMOD_PARTS;
+            v[q] = wsq_t[(int64_t)min(i, cin - 1) * cout + coc];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = c0 + part + q * DEMOD_PARTS;
+            if (i < cin) {
+#pragma unroll
+                for (int g = 0; g < DEMOD_MAX_N; ++g)
+                    if (g < n) acc[g] += s_s[g * cin + i] * v[q];
+            }
+        }
+    }
+    for (int g = 0; g < n; ++g) {
+        s_p[part * DEMOD_COLS + col] = acc[g];
+        __syncthreads();
+        if (part == 0 && co < cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < DEMOD_PARTS; ++q) t += s_p[q * DEMOD_COLS + col];
+            dcoefs[(int64_t)g * cout + co] = rsqrtf(t + 1e-8f);
+        }
+        __syncthreads();
     }
 }
 
@@ -94,8 +171,9 @@ fold_heads_kernel(const float* __restrict__ w, int64_t w_stride, int cin, int wd
     const int nci = min(FOLD_CI, cin - ci0);
     for (int k = threadIdx.x; k < wdim; k += blockDim.x) s_w[k] = w[(int64_t)img * w_stride + k];
     __syncthreads();
-    affine_rows(s_w, A0 + (int64_t)ci0 * wdim, b0 ? b0 + ci0 : nullptr, nci, wdim, a_gain, 1.0f, gain0, s0);
-    affine_rows(s_w, A1 + (int64_t)ci0 * wdim, b1 ? b1 + ci0 : nullptr, nci, wdim, a_gain, 1.0f, gain1, s1);
+    // 16 waves: waves 0-7 take head 0 (8 rows each), waves 8-15 head 1 — both heads' rows are in flight together
+    if ((threadIdx.x >> 6) < 8) affine_rows_half<0>(s_w, A0 + (int64_t)ci0 * wdim, b0 ? b0 + ci0 : nullptr, nci, wdim, a_gain, gain0, s0);
+    else                        affine_rows_half<1>(s_w, A1 + (int64_t)ci0 * wdim, b1 ? b1 + ci0 : nullptr, nci, wdim, a_gain, gain1, s1);
     __syncthreads();
     float* o = out + (int64_t)img * (cout0 + cout1) * cin;
     for (int e = threadIdx.x; e < (cout0 + cout1) * FOLD_CI; e += blockDim.x) {
@@ -115,13 +193,18 @@ extern "C" int ide3d_style_demod(const float* w, int64_t w_stride, const float* 
     IDE3D_CHECK_ARG(w && affine_w && styles, "style_demod: null pointer");
     IDE3D_CHECK_ARG(dcoefs == nullptr || wsq_t != nullptr, "style_demod: dcoefs needs wsq_t");
     IDE3D_CHECK_ARG(n > 0 && cin > 0 && wdim > 0 && (dcoefs == nullptr || cout > 0), "style_demod: bad shape");
-    IDE3D_CHECK_ARG((size_t)wdim * sizeof(float) <= 60 * 1024 && ((size_t)cin + 1024) * sizeof(float) <= 60 * 1024,
-                    "style_demod: w_dim / cin too large for LDS staging");
-    hipLaunchKernelGGL(style_affine_kernel, dim3(cdiv(cin, STYLE_ROWS), n), dim3(512), (size_t)wdim * sizeof(float), (hipStream_t)stream,
+    IDE3D_CHECK_ARG((size_t)wdim * sizeof(float) <= 60 * 1024, "style_demod: w_dim too large for LDS staging");
+    IDE3D_CHECK_ARG(dcoefs == nullptr || ((size_t)DEMOD_MAX_N * cin + DEMOD_PARTS * DEMOD_COLS) * sizeof(float) <= 60 * 1024,
+                    "style_demod: cin too large for LDS staging");
+    hipLaunchKernelGGL(style_affine_kernel, dim3(cdiv(cin, STYLE_ROWS), n), dim3(256), (size_t)wdim * sizeof(float), (hipStream_t)stream,
                        w, w_stride, affine_w, affine_b, cin, wdim, affine_gain, bias_gain, styles);
     if (dcoefs)
-        hipLaunchKernelGGL(style_demod_kernel, dim3(cdiv(cout, 64), n), dim3(1024), ((size_t)cin + 1024) * sizeof(float), (hipStream_t)stream,
-                           styles, wsq_t, cin, cout, dcoefs);
+        for (int g0 = 0; g0 < n; g0 += DEMOD_MAX_N) {            // DEMOD_MAX_N images per launch share one pass over wsq_t
+            const int ng = min(DEMOD_MAX_N, n - g0);
+            hipLaunchKernelGGL(style_demod_kernel, dim3(cdiv(cout, DEMOD_COLS)), dim3(1024),
+                               ((size_t)ng * cin + DEMOD_PARTS * DEMOD_COLS) * sizeof(float), (hipStream_t)stream,
+                               styles + (int64_t)g0 * cin, wsq_t, ng, cin, cout, dcoefs + (int64_t)g0 * cout);
+        }
     IDE3D_CHECK_LAUNCH("style_demod");
     return IDE3D_OK;
 }

@@ -434,3 +434,38 @@ def test_frame_u8(golden, gpu_device):
     img = torch.randn(3, 3, 64, 128, generator=g); seg = torch.randn(3, 19, 64, 128, generator=g)
     out = hip_plugin.FramePlugin.frame_u8(img.to(gpu_device), seg.to(gpu_device), pal).cpu().numpy()
     assert np.array_equal(out, oracle_ops.frame_u8(img, seg))
+
+
+# ---- style preparation (affine styles, demodulation coefficients, folded head weights) ---------------------------------
+
+def test_style_demod_and_fold_heads_vs_formula(gpu_device):
+    """`ide3d_style_demod` / `ide3d_fold_heads` == the framework formulas of networks.py:52-60,91-93,700-706 (fp64 reference),
+    over batch sizes that cross the 8-images-per-launch grouping, channel counts that are not multiples of the block sizes,
+    strided ws rows and the tiny w_dim."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(31)
+    for n, cin, cout, wdim in ((4, 512, 512, 512), (9, 48, 40, 32), (1, 128, 64, 512), (3, 64, 22, 36)):
+        ws = torch.randn(n, 3, wdim, generator=g).to(gpu_device)
+        w = ws[:, 1]                                                    # strided rows, unit inner stride
+        A = torch.randn(cin, wdim, generator=g).to(gpu_device)
+        b = torch.randn(cin, generator=g).to(gpu_device)
+        W = torch.randn(cout, cin, 3, 3, generator=g).to(gpu_device)
+        wsq_t = W.double().square().sum(dim=[2, 3]).t().contiguous().float()
+        a_gain, b_gain = 1 / math.sqrt(wdim), 1.0
+        styles, dcoefs = hip_plugin.StylePlugin.style_demod(w, A, b, a_gain, b_gain, wsq_t)
+        s_ref = w.double() @ (A.double() * a_gain).t() + b.double() * b_gain
+        d_ref = ((W.double().unsqueeze(0) * s_ref.reshape(n, 1, cin, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+        assert_close(styles, s_ref.float().cpu(), rtol=2e-5, atol=2e-5, what=f'styles {n, cin, cout, wdim}')
+        assert_close(dcoefs, d_ref.float().cpu(), rtol=1e-4, atol=1e-7, what=f'dcoefs {n, cin, cout, wdim}')
+        only, none = hip_plugin.StylePlugin.style_demod(w, A, b, a_gain, b_gain, None)
+        assert none is None and torch.equal(only, styles)
+        # two heads (rgb 3, seg 19) folded into per-image 1x1 weights
+        A1 = torch.randn(cin, wdim, generator=g).to(gpu_device); b1 = torch.randn(cin, generator=g).to(gpu_device)
+        W0 = torch.randn(3, cin, generator=g).to(gpu_device); W1 = torch.randn(19, cin, generator=g).to(gpu_device)
+        g0, g1 = 1 / math.sqrt(cin), 0.5 / math.sqrt(cin)
+        out = hip_plugin.StylePlugin.fold_heads(w, a_gain, A, b, W0, g0, A1, b1, W1, g1)
+        s0 = (w.double() @ (A.double() * a_gain).t() + b.double()) * g0
+        s1 = (w.double() @ (A1.double() * a_gain).t() + b1.double()) * g1
+        ref = torch.cat([W0.double().unsqueeze(0) * s0.unsqueeze(1), W1.double().unsqueeze(0) * s1.unsqueeze(1)], dim=1)
+        assert out.shape == (n, 22, cin, 1, 1)
+        assert_close(out.reshape(n, 22, cin), ref.float().cpu(), rtol=2e-5, atol=2e-5, what=f'fold_heads {n, cin, wdim}')
