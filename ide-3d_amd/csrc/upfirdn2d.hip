@@ -36,6 +36,54 @@ apply_epilogue(typename Elem<T>::math_t v, const ide3d_upfirdn2d_epilogue& ep, i
     return v;
 }
 
+// Epilogue of NO consecutive outputs of one row (tile kernel): the per-row pointers are formed once, the skip / noise
+// operands come in as one 16-byte load when the four outputs are in bounds and aligned, the bias is a scalar.
+template <class T, int NO>
+__device__ __forceinline__ void epilogue_row(typename Elem<T>::math_t (&row)[NO], const ide3d_upfirdn2d_epilogue& ep,
+                                             const T* add_plane, typename Elem<T>::math_t bias, int oy, int ox0, int out_w, bool full) {
+    using M = typename Elem<T>::math_t;
+    if (ep.add) {
+        const T* ap = add_plane + (int64_t)oy * ep.add_stride[2];
+        if constexpr (sizeof(T) == 4 && NO == 4) {
+            if (full && ep.add_stride[3] == 1 && ((reinterpret_cast<uintptr_t>(ap + ox0) & 15) == 0)) {
+                const float4 a = *reinterpret_cast<const float4*>(ap + ox0);
+                row[0] += a.x; row[1] += a.y; row[2] += a.z; row[3] += a.w;
+                goto add_done;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= 0 && ox < out_w) row[j] += Elem<T>::ld(ap + (int64_t)ox * ep.add_stride[3]);
+        }
+    }
+add_done:
+    if (ep.noise) {
+        const float* np_ = ep.noise + (int64_t)oy * out_w;
+        if (NO == 4 && full && ((reinterpret_cast<uintptr_t>(np_ + ox0) & 15) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(np_ + ox0);
+            row[0] += (M)(a.x * ep.noise_strength); row[1] += (M)(a.y * ep.noise_strength);
+            row[2] += (M)(a.z * ep.noise_strength); row[3] += (M)(a.w * ep.noise_strength);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int ox = ox0 + j;
+                if (ox >= 0 && ox < out_w) row[j] += (M)(np_[ox] * ep.noise_strength);
+            }
+        }
+    }
+    if (ep.fused_act) {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            M v = row[j] + bias;
+            if (ep.act == 3) v = (v > 0) ? v : v * (M)ep.alpha;
+            v *= (M)ep.act_gain;
+            if (ep.clamp >= 0.f) v = (v > (M)ep.clamp) ? (M)ep.clamp : ((v < -(M)ep.clamp) ? -(M)ep.clamp : v);
+            row[j] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic kernel
 // ------------------------------------------------------------------------------------------------
@@ -149,13 +197,30 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
     const int in_y0 = (UY > 1) ? qy0 : qy0 * DY - p.pad_y0;
 
     const T* __restrict__ xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int iy = in_y0 + ly, ix = in_x0 + lx;
-        M v = 0;
-        if (lx < AX::window(TCX) && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
-            v = Elem<T>::ld(xp + iy * p.x_stride[2] + ix);
-        s_in[i] = v;
+    // Stage the input window: every load is unconditional (coordinates clamped into the image, out-of-image and
+    // padding elements zeroed by a select afterwards) and all of a thread's loads are issued before the first LDS
+    // write — conditional loads would each sit behind their own exec-mask branch and `s_waitcnt`.
+    {
+        constexpr int NLD = (LH * LW + 255) / 256;
+        constexpr int DROW = 256 / LW, DCOL = 256 % LW;          // element i + 256 is DROW rows and DCOL columns further
+        M v[NLD];
+        int ly = (int)threadIdx.x / LW, lx = (int)threadIdx.x % LW;
+        static_assert(NLD <= 64, "staging loads per thread must fit the validity mask");
+        unsigned long long okbits = 0;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int iy = in_y0 + ly, ix = in_x0 + lx;
+            const int cy_ = min(max(iy, 0), p.in_h - 1), cx_ = min(max(ix, 0), p.in_w - 1);
+            v[k] = Elem<T>::ld(xp + cy_ * p.x_stride[2] + cx_);
+            okbits |= (lx < AX::window(TCX) && iy == cy_ && ix == cx_ && ly < LH) ? (1ull << k) : 0ull;
+            lx += DCOL; ly += DROW;
+            if (lx >= LW) { lx -= LW; ++ly; }
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            if (i < LH * LW) s_in[i] = ((okbits >> k) & 1ull) ? v[k] : (M)0;
+        }
     }
     __syncthreads();
 
@@ -170,6 +235,8 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
             win[wy][wx] = s_in[(ly0 + wy) * LW + lx0 + wx];
 
     T* __restrict__ yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
+    const T* add_plane = ep.add ? (const T*)ep.add + (int64_t)n * ep.add_stride[0] + (int64_t)c * ep.add_stride[1] : nullptr;
+    const M bias = (ep.fused_act && ep.bias) ? (M)Elem<T>::ld((const T*)ep.bias + c) : (M)0;
 #pragma unroll
     for (int cy = 0; cy < CY; ++cy)
 #pragma unroll
@@ -198,13 +265,10 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
             const int ox0 = (UX > 1) ? qx * UX + p.pad_x0 : qx;
             T* yr = yp + oy * p.y_stride[2];
             constexpr int NO = CX * UX;
-#pragma unroll
-            for (int j = 0; j < NO; ++j) {
-                const int ox = ox0 + j;
-                if (ox >= 0 && ox < p.out_w) row[j] = apply_epilogue<T>(row[j], ep, n, c, oy, ox, p.out_w);
-            }
+            const bool full = ox0 >= 0 && ox0 + NO <= p.out_w;
+            epilogue_row<T, NO>(row, ep, add_plane, bias, oy, ox0, p.out_w, full);
             if constexpr (sizeof(T) == 4 && NO == 4) {
-                if (ox0 >= 0 && ox0 + NO <= p.out_w && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
+                if (full && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
                     float4 v4 = make_float4(row[0], row[1], row[2], row[3]);
                     *reinterpret_cast<float4*>(yr + ox0) = v4;
                     continue;
@@ -252,8 +316,12 @@ static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilo
     const bool w_contig = (p.x_stride[3] == 1 && p.y_stride[3] == 1);
     if constexpr (!std::is_same<T, double>::value) {
         if (w_contig && p.f_w == 4 && p.f_h == 4) {
-            if (p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1)
-                return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 2>(p, ep, st);
+            if (p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1) {
+                // 4 output rows per thread: 7 window rows serve 4 rows (halo 9 % instead of 19 %); narrow images get a
+                // 64-wide tile so that lanes are not wasted on columns that do not exist
+                if (p.out_w <= 64) return launch_tile<T, 1, 1, 1, 1, 4, 4, 2, 4>(p, ep, st);
+                return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 4>(p, ep, st);
+            }
             if (p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1)
                 return launch_tile<T, 2, 2, 1, 1, 4, 4, 2, 2>(p, ep, st);
             if (p.up_x == 1 && p.up_y == 1 && p.down_x == 2 && p.down_y == 2)
