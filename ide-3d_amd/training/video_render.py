@@ -1,0 +1,97 @@
+"""Grid video sweep: the frame loop of `gen_videos.gen_interp_video` (gen_videos.py:66-131) on the HIP rendering path.
+
+Same schedule as the reference — keyframe latents per grid cell, `scipy.interpolate.interp1d` of the keyframe `ws` over
+time (`kind='cubic'`, `wraps` periodic copies), one look-at camera per frame sweeping yaw by sin and pitch by cos
+(gen_videos.py:118-122), `image_mode='image_seg'` frames = RGB | colourised segmentation laid out as a grid — but
+  * all grid cells of a frame are rendered in ONE batched `G.synthesis` call (the reference renders them one by one),
+  * when a cell's `ws` does not change over time (one keyframe per cell, the BASELINE config-3 case) its two tri-planes
+    are computed once and reused for every pose (`cached_planes`: the `vb*` backbone is 2/3 of the frame's FLOPs),
+  * colour mapping + grid layout happen on the GPU in uint8 (`frames_u8` / `ide3d_frame_u8`) — the encoder
+    (imageio / libx264, gen_videos.py:108,131) is a host-side consumer and out of scope: frames are yielded.
+"""
+
+import math
+from typing import Iterator, Sequence, Tuple
+
+import numpy as np
+import scipy.interpolate
+import torch
+
+from training import distributed_render as dr
+from training import triplane
+from training.volumetric_rendering import LookAtPoseSampler
+
+INTRINSICS = ((4.2647, 0, 0.5), (0, 4.2647, 0.5), (0, 0, 1))          # gen_videos.py:90
+
+
+def sweep_pose(frame_idx: int, total_frames: int, lookat, radius: float = 2.7, yaw_range: float = 0.5, pitch_range: float = 0.25,
+               device='cpu') -> torch.Tensor:
+    """25-D camera label of frame `frame_idx` (gen_videos.py:116-125)."""
+    t = 2 * math.pi * frame_idx / total_frames
+    cam2world = LookAtPoseSampler.sample(math.pi / 2 - yaw_range * np.sin(t), math.pi / 2 - 0.05 + pitch_range * np.cos(t),
+                                         lookat, radius=radius, device=device)
+    intr = torch.tensor(INTRINSICS, dtype=torch.float32, device=device)
+    return torch.cat([cam2world.reshape(-1, 16), intr.reshape(-1, 9)], 1)
+
+
+def interpolate_ws(ws_keyframes: np.ndarray, w_frames: int, kind: str = 'cubic', wraps: int = 2) -> np.ndarray:
+    """ws of one grid cell for every frame: [num_keyframes * w_frames, num_ws, w_dim] (gen_videos.py:95-104,127-128)."""
+    k = ws_keyframes.shape[0]
+    x = np.arange(-k * wraps, k * (wraps + 1))
+    y = np.tile(ws_keyframes, [wraps * 2 + 1, 1, 1])
+    interp = scipy.interpolate.interp1d(x, y, kind=kind, axis=0)
+    return np.stack([interp(f / w_frames) for f in range(k * w_frames)]).astype(np.float32)
+
+
+def layout_u8(frames: torch.Tensor, grid_w: int, grid_h: int) -> torch.Tensor:
+    """uint8 [grid_h * grid_w, H, W', 3] cell frames -> [grid_h * H, grid_w * W', 3] (layout_grid, gen_videos.py:24-38)."""
+    n, h, w, c = frames.shape
+    assert n == grid_w * grid_h
+    return frames.reshape(grid_h, grid_w, h, w, c).permute(0, 2, 1, 3, 4).reshape(grid_h * h, grid_w * w, c)
+
+
+@torch.no_grad()
+def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int = 60 * 4, kind: str = 'cubic',
+                      grid_dims: Tuple[int, int] = (1, 1), num_keyframes=None, wraps: int = 2, psi: float = 1, truncation_cutoff=14,
+                      cfg: str = 'FFHQ', image_mode: str = 'image_seg', device=torch.device('cuda'), noise_mode: str = 'const',
+                      cache_static_planes: bool = True, **synthesis_kwargs) -> Iterator[torch.Tensor]:
+    """Yields one uint8 grid frame [grid_h * H, grid_w * W', 3] per video frame (W' = 2 W for 'image_seg', else W).
+    `synthesis_kwargs` go to `G.synthesis` (e.g. `ray_jitter=False` for reproducible frames: like the reference, the
+    default draws fresh stratified jitter for every frame)."""
+    grid_w, grid_h = grid_dims
+    cells = grid_w * grid_h
+    if num_keyframes is None:
+        if len(seeds) % cells != 0:
+            raise ValueError('Number of input seeds must be divisible by grid W*H')
+        num_keyframes = len(seeds) // cells
+    if image_mode not in ('image', 'image_seg'):
+        raise ValueError("image_mode must be 'image' or 'image_seg'")
+    all_seeds = np.array([seeds[i % len(seeds)] for i in range(num_keyframes * cells)], dtype=np.int64)
+    if shuffle_seed is not None:
+        np.random.RandomState(seed=shuffle_seed).shuffle(all_seeds)
+    lookat = torch.tensor([0, 0, 0.2] if cfg == 'FFHQ' else [0, 0, 0], dtype=torch.float32, device=device)
+
+    zs = torch.from_numpy(np.stack([np.random.RandomState(int(s)).randn(G.z_dim) for s in all_seeds])).to(device).float()
+    front = LookAtPoseSampler.sample(math.pi / 2, math.pi / 2, lookat, radius=2.7, device=device)
+    c_front = torch.cat([front.reshape(-1, 16), torch.tensor(INTRINSICS, dtype=torch.float32, device=device).reshape(-1, 9)], 1)
+    ws = G.mapping(zs, c_front.repeat(len(zs), 1), truncation_psi=psi, truncation_cutoff=truncation_cutoff)
+    ws = ws.reshape(grid_h, grid_w, num_keyframes, *ws.shape[1:]).cpu().numpy()
+    total = num_keyframes * w_frames
+    # [cell][frame] ws, uploaded once
+    ws_frames = torch.from_numpy(np.stack([interpolate_ws(ws[yi][xi], w_frames, kind, wraps)
+                                           for yi in range(grid_h) for xi in range(grid_w)])).to(device)
+    # one keyframe per cell: the spline through copies of one point is that point (up to interpolation round-off)
+    static = cache_static_planes and num_keyframes == 1 and bool(torch.allclose(ws_frames, ws_frames[:, :1].expand_as(ws_frames), atol=1e-5))
+    planes = None
+    if static:
+        voxel_ws, _ = G.synthesis.split_ws(ws_frames[:, 0])
+        planes = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode, force_fp32=True)
+    palette = dr.palette_tensor(G.synthesis.seg_channels, device)
+    for frame_idx in range(total):
+        c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)
+        img, seg = G.synthesis(ws_frames[:, frame_idx], c=c, noise_mode=noise_mode, return_seg=True, cached_planes=planes, **synthesis_kwargs)
+        if image_mode == 'image_seg':
+            cell_frames = dr.frames_u8(img, seg, palette)
+        else:
+            cell_frames = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        yield layout_u8(cell_frames, grid_w, grid_h)

@@ -183,6 +183,22 @@ def test_extract_shapes_density_cube(golden, gpu_device):
     _rel(torch.from_numpy(got).reshape(-1), ref, 5e-4, 'driver density cube')
 
 
+def test_video_sweep_gpu_vs_cpu(golden):
+    """gen_videos.py 2x2 grid sweep (training.video_render) on the GPU == the same driver on the CPU definitions."""
+    from training import video_render
+    gpu = torch.device('cuda:0')
+    G, cfg, a = _load(golden, gpu)
+    Gc, _, _ = _load(golden, 'cpu')
+    kw = dict(w_frames=2, grid_dims=(2, 2), psi=0.7, truncation_cutoff=None, ray_jitter=False)
+    fg = list(video_render.gen_interp_frames(G, [3, 5, 7, 11], device=gpu, **kw))
+    fc = list(video_render.gen_interp_frames(Gc, [3, 5, 7, 11], device=torch.device('cpu'), **kw))
+    assert _calls('frame_u8') >= 2 and _calls('render_rays') >= 2
+    for x, y in zip(fg, fc):
+        assert x.shape == y.shape == (128, 256, 3)
+        diff = (x.cpu().int() - y.int()).abs()
+        assert (diff > 1).float().mean() < 5e-3
+
+
 def test_hipgraph_replay_equals_eager(golden, gpu_device):
     """GraphedRenderer (hipGraph replay of mapping + synthesis) == eager launches, bit for bit, over changing inputs."""
     from training import triplane

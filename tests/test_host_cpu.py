@@ -235,6 +235,46 @@ def test_shape_extraction_cpu(golden):
     assert np.array_equal(one, cube)
 
 
+def test_video_sweep_cpu(golden):
+    """gen_videos.py frame loop (training.video_render): batched cells + cached tri-planes == the reference's schedule
+    rendered cell by cell (batch 1, no caching), camera sweep == direct LookAtPoseSampler calls, ws interpolation == scipy."""
+    import scipy.interpolate
+    from training import video_render as vr_, triplane, distributed_render as dr
+    from training.volumetric_rendering import LookAtPoseSampler
+    (cfg, a), = golden('generator_tiny').cases
+    G = triplane.TriPlaneGenerator(triplane.tiny_spec()).eval()
+    G.load_state_dict({k[len('sd_'):]: t(v) for k, v in a.items() if k.startswith('sd_')})
+    seeds, w_frames, grid = [3, 5, 7, 11], 3, (2, 2)
+    frames = list(vr_.gen_interp_frames(G, seeds, w_frames=w_frames, grid_dims=grid, psi=0.7, truncation_cutoff=None, device=torch.device('cpu'),
+                                       ray_jitter=False))
+    assert len(frames) == w_frames and frames[0].shape == (2 * 64, 2 * 128, 3) and frames[0].dtype == torch.uint8
+    lookat = torch.tensor([0, 0, 0.2])
+    front = LookAtPoseSampler.sample(math.pi / 2, math.pi / 2, lookat, radius=2.7)
+    intr = torch.tensor(vr_.INTRINSICS, dtype=torch.float32).reshape(1, 9)
+    c0 = torch.cat([front.reshape(1, 16), intr], 1)
+    with torch.no_grad():
+        for f in range(w_frames):
+            ang = 2 * math.pi * f / w_frames
+            pose = LookAtPoseSampler.sample(math.pi / 2 - 0.5 * np.sin(ang), math.pi / 2 - 0.05 + 0.25 * np.cos(ang), lookat, radius=2.7)
+            c = torch.cat([pose.reshape(1, 16), intr], 1)
+            assert torch.equal(vr_.sweep_pose(f, w_frames, lookat), c)
+            cells = []
+            for s in seeds:
+                z = torch.from_numpy(np.random.RandomState(s).randn(1, G.z_dim)).float()
+                ws = G.mapping(z, c0, truncation_psi=0.7)
+                img, seg = G.synthesis(ws, c=c, noise_mode='const', return_seg=True, ray_jitter=False)
+                cells.append(dr.frames_u8(img, seg)[0])
+            ref = torch.cat([torch.cat(cells[:2], dim=1), torch.cat(cells[2:], dim=1)], dim=0)
+            diff = (frames[f].int() - ref.int()).abs()
+            # RGB differs by at most 1 LSB from batch-composition rounding; a flipped arg-max at a class boundary recolours a pixel
+            assert (diff > 1).float().mean() < 5e-3, f'frame {f}: {(diff > 1).float().mean():.4f} of the bytes differ by more than 1'
+    # interpolation of two keyframes == scipy on the tiled sequence
+    g = np.random.RandomState(0).randn(2, 4, 6).astype(np.float32)
+    got = vr_.interpolate_ws(g, 4)
+    x = np.arange(-4, 6); ref_i = scipy.interpolate.interp1d(x, np.tile(g, [5, 1, 1]), kind='cubic', axis=0)
+    assert got.shape == (8, 4, 6) and np.allclose(got[5], ref_i(5 / 4), atol=1e-6) and np.allclose(got[0], g[0], atol=1e-6)
+
+
 def test_full_spec_shapes():
     from training import triplane
     sp = triplane.GeneratorSpec()
