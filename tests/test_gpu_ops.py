@@ -469,3 +469,35 @@ def test_style_demod_and_fold_heads_vs_formula(gpu_device):
         ref = torch.cat([W0.double().unsqueeze(0) * s0.unsqueeze(1), W1.double().unsqueeze(0) * s1.unsqueeze(1)], dim=1)
         assert out.shape == (n, 22, cin, 1, 1)
         assert_close(out.reshape(n, 22, cin), ref.float().cpu(), rtol=2e-5, atol=2e-5, what=f'fold_heads {n, cin, wdim}')
+
+
+def test_upfirdn2d_fused_epilogue(gpu_device):
+    """`ide3d_upfirdn2d_ex`: FIR + (skip add | noise * strength | bias + lrelu * gain + clamp) in the store of the FIR ==
+    the separate reference ops (upfirdn2d.py:167 + networks.py:404-414 / 1100-1121), on shapes that hit aligned 16-byte
+    rows, ragged row ends, odd widths (scalar epilogue), the 64-wide tile, and the generic kernel (5-tap filter)."""
+    from torch_utils import hip_plugin
+    from torch_utils.ops import upfirdn2d as up, bias_act
+    g = torch.Generator().manual_seed(41)
+    P = hip_plugin.Upfirdn2dPlugin
+    f4 = up.setup_filter([1, 3, 3, 1], device=gpu_device)
+    f5 = up.setup_filter([1, 4, 6, 4, 1], device=gpu_device)
+    # post-transposed-conv FIR (up 1, pad 1, gain 4) + noise + bias + lrelu + clamp
+    for shape, f in (((2, 5, 65, 65), f4), ((1, 3, 131, 131), f4), ((2, 4, 38, 43), f4), ((1, 2, 21, 30), f5)):
+        x = torch.randn(*shape, generator=g).to(gpu_device)
+        pad = 1 if f is f4 else 2
+        oh, ow = shape[2] + 2 * pad - f.shape[0] + 1, shape[3] + 2 * pad - f.shape[0] + 1
+        noise = torch.randn(oh, ow, generator=g).to(gpu_device)
+        b = torch.randn(shape[1], generator=g).to(gpu_device)
+        got = P.upfirdn2d_ex(x, f, 1, 1, 1, 1, pad, pad, pad, pad, False, 4.0, noise=noise, noise_strength=0.37, bias=b, act=3, alpha=0.2,
+                             act_gain=math.sqrt(2), clamp=1.5)
+        ref = up._upfirdn2d_ref(x.cpu().double(), f.cpu(), padding=[pad] * 4, gain=4)
+        ref = bias_act._bias_act_ref(ref + noise.cpu().double() * 0.37, b.cpu().double(), act='lrelu', gain=math.sqrt(2), clamp=1.5)
+        assert_close(got, ref.float(), rtol=1e-5, atol=1e-5, what=f'fir+noise+bias_act {shape}')
+    # skip-image upsample (up 2, pad [2,1,2,1], gain 4) + add, with a non-contiguous addend
+    for shape in ((2, 22, 16, 16), (1, 3, 33, 20), (3, 96, 8, 8)):
+        x = torch.randn(*shape, generator=g).to(gpu_device)
+        big = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3] + 3, generator=g).to(gpu_device)
+        for add in (big[..., :2 * shape[3]].contiguous(), big[..., 1:2 * shape[3] + 1]):
+            got = P.upfirdn2d_ex(x, f4, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0, add=add)
+            ref = up._upfirdn2d_ref(x.cpu().double(), f4.cpu(), up=2, padding=[2, 1, 2, 1], gain=4) + add.cpu().double()
+            assert_close(got, ref.float(), rtol=1e-5, atol=1e-5, what=f'up2+add {shape}')
