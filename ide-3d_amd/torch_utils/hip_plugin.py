@@ -15,6 +15,7 @@ different arch, or a launch fails, a RuntimeError is raised.
 import ctypes
 import os
 import threading
+import weakref
 
 import torch
 
@@ -636,7 +637,7 @@ class VolumeRenderPlugin:
 
 
 class ModconvPlugin:
-    # workspace cache: (weight data_ptr, shape, n, h, w, mode) -> [buffer, weight._version the packed copy was made from]
+    # workspace cache: (weight data_ptr, shape, n, h, w, mode) -> [buffer, weight._version the packed copy was made from, weakref(weight)]
     _ws = {}
 
     @staticmethod
@@ -663,7 +664,7 @@ class ModconvPlugin:
             _require(nbytes >= 0, 'modconv2d: unsupported configuration')
             if len(ModconvPlugin._ws) > 256:
                 ModconvPlugin._ws.clear()
-            ent = [torch.empty([max(nbytes // 4, 1)], dtype=torch.float32, device=x.device), None]
+            ent = [torch.empty([max(nbytes // 4, 1)], dtype=torch.float32, device=x.device), None, None]
             ModconvPlugin._ws[key] = ent
         p = _ModconvParams()
         p.x, p.w, p.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
@@ -677,13 +678,15 @@ class ModconvPlugin:
         p.noise_strength = float(noise_strength)
         p.act, p.alpha, p.gain, p.clamp = int(act), float(alpha), float(gain), float(clamp)
         p.mode = mode
-        p.weights_packed = int((not per_image) and ent[1] == w._version)
+        # the packed copy in the workspace is valid only for the very tensor object (and version) it was made from: a data_ptr
+        # can be recycled by the allocator for another weight of the same shape
+        p.weights_packed = int((not per_image) and ent[2] is not None and ent[2]() is w and ent[1] == w._version)
         p.w_batch_stride = (cout * cin * k * k) if per_image else 0
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         with torch.cuda.device(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
-        ent[1] = None if per_image else w._version
+        ent[1], ent[2] = (None, None) if per_image else (w._version, weakref.ref(w))
         return y
 
 

@@ -501,3 +501,31 @@ def test_upfirdn2d_fused_epilogue(gpu_device):
             got = P.upfirdn2d_ex(x, f4, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0, add=add)
             ref = up._upfirdn2d_ref(x.cpu().double(), f4.cpu(), up=2, padding=[2, 1, 2, 1], gain=4) + add.cpu().double()
             assert_close(got, ref.float(), rtol=1e-5, atol=1e-5, what=f'up2+add {shape}')
+
+
+def test_modconv2d_packed_weight_cache_is_identity_safe(gpu_device):
+    """The packed-weight workspace is reused only for the same tensor object at the same version: an in-place update, or a
+    different weight that lands on a recycled address, must be re-packed."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(1, 16, 16, 16, generator=g).to(gpu_device)
+    s = torch.ones(1, 16, device=gpu_device)
+
+    def run(w):
+        return hip_plugin.ModconvPlugin.modconv2d(x, w, s, None, None, 0.0, None, 1, 0.0, 1.0, -1.0)
+
+    def ref(w):
+        return torch.nn.functional.conv2d(x, w, padding=1)
+
+    w1 = torch.randn(32, 16, 3, 3, generator=g).to(gpu_device)
+    assert_close(run(w1), ref(w1).cpu(), rtol=1e-4, atol=1e-4, what='first weight')
+    assert_close(run(w1), ref(w1).cpu(), rtol=1e-4, atol=1e-4, what='cached pack')
+    w1.mul_(2.0)                                                   # in-place update bumps _version
+    assert_close(run(w1), ref(w1).cpu(), rtol=1e-4, atol=1e-4, what='after in-place update')
+    ptr = w1.data_ptr()
+    del w1
+    for _ in range(8):                                             # the caching allocator hands the block out again
+        w2 = torch.randn(32, 16, 3, 3, generator=g).to(gpu_device)
+        if w2.data_ptr() == ptr:
+            break
+    assert_close(run(w2), ref(w2).cpu(), rtol=1e-4, atol=1e-4, what='new weight (possibly at the recycled address)')
