@@ -15,6 +15,8 @@ with the FIR, the demodulation/noise and the bias-activation on HIP kernels.  Wi
 evaluate the same mathematics through differentiable ops.
 """
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -49,15 +51,15 @@ def _style_init():
 
 
 def _wsq_t(weight):
-    """[Cin, Cout] = sum_k W[o, i, k]^2 transposed, cached per weight version (inference only)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    """[Cin, Cout] = sum_k W[o, i, k]^2 transposed, cached per weight tensor and version (inference only).  An entry is
+    valid only for the tensor object it was computed from (ids and storage addresses get recycled) at the same `_version`."""
     ent = _wsq_cache.get(id(weight))
-    if ent is None or ent[0] != key:
+    if ent is None or ent[0]() is not weight or ent[1] != weight._version:
         if len(_wsq_cache) > 512:
             _wsq_cache.clear()
-        ent = (key, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
+        ent = (weakref.ref(weight), weight._version, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
         _wsq_cache[id(weight)] = ent
-    return ent[1]
+    return ent[2]
 
 
 def _styles_and_dcoefs(affine, w, weight, demodulate):
@@ -97,15 +99,7 @@ def _demod_coefs(weight, styles):
     if torch.is_grad_enabled() and weight.requires_grad:
         wsq_t = weight.square().sum(dim=[2, 3]).t()       # [I, O]
     else:
-        # sum_k w^2 only depends on the weights: cached per (storage, version), recomputed after any in-place update
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
-        ent = _wsq_cache.get(id(weight))
-        if ent is None or ent[0] != key:
-            if len(_wsq_cache) > 512:
-                _wsq_cache.clear()
-            ent = (key, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
-            _wsq_cache[id(weight)] = ent
-        wsq_t = ent[1]
+        wsq_t = _wsq_t(weight)       # sum_k w^2 only depends on the weights: cached, recomputed after any in-place update
     return torch.addmm(_eps_like(styles), styles.square(), wsq_t).rsqrt()     # [N, O]
 
 
