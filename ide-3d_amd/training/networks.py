@@ -104,6 +104,23 @@ def _demod_coefs(weight, styles):
 
 
 _wsq_cache = {}
+_noise_cache = {}
+
+
+def _scaled_const_noise(noise_const, noise_strength):
+    """noise_const * noise_strength.  In inference both are fixed, so the product is formed once per (tensor objects,
+    versions) instead of by one element-wise launch per layer and frame; with autograd it is the plain product."""
+    if torch.is_grad_enabled() and (noise_strength.requires_grad or noise_const.requires_grad):
+        return noise_const * noise_strength
+    ent = _noise_cache.get(id(noise_const))
+    if (ent is None or ent[0]() is not noise_const or ent[1]() is not noise_strength
+            or ent[2] != (noise_const._version, noise_strength._version, noise_const.device)):
+        if len(_noise_cache) > 512:
+            _noise_cache.clear()
+        ent = (weakref.ref(noise_const), weakref.ref(noise_strength), (noise_const._version, noise_strength._version, noise_const.device),
+               (noise_const * noise_strength).detach())
+        _noise_cache[id(noise_const)] = ent
+    return ent[3]
 _eps_cache = {}
 
 
@@ -385,7 +402,7 @@ class SynthesisLayer(torch.nn.Module):
                 noise = torch.randn([x.shape[0], 1, self.up * x.shape[2], self.up * x.shape[3]], device=x.device) * self.noise_strength
             elif noise_mode == 'const':
                 const_noise = self.noise_const.shape[-1] >= self.up * x.shape[3]
-                noise = self.noise_const * self.noise_strength
+                noise = _scaled_const_noise(self.noise_const, self.noise_strength)
                 if not const_noise:
                     noise = noise.repeat(1, self.up * x.shape[3] // noise.shape[-1])
 
