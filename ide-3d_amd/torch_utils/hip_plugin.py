@@ -653,7 +653,6 @@ class ModconvPlugin:
         cout, cin2, k, k2 = w.shape[-4:]
         _require(cin == cin2 and k == k2 and k in (1, 3), 'modconv2d: weight must be [cout, cin, k, k] with k in {1, 3}')
         _require(mode in (0, 2), 'modconv2d: mode must be 0 or 2')
-        _require(per_image or styles is not None, 'modconv2d: styles required')
         oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (h, wd)
         y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
         lib = load()

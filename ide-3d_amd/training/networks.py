@@ -105,6 +105,19 @@ def _demod_coefs(weight, styles):
 
 _wsq_cache = {}
 _noise_cache = {}
+_wscale_cache = {}
+
+
+def _scaled_weight(weight, gain):
+    """weight * gain (the equalised-learning-rate factor), formed once per (tensor object, version) in inference so that
+    the packed copy inside the HIP workspace stays valid across calls."""
+    ent = _wscale_cache.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != (weight._version, float(gain)):
+        if len(_wscale_cache) > 512:
+            _wscale_cache.clear()
+        ent = (weakref.ref(weight), (weight._version, float(gain)), (weight.detach() * gain).contiguous())
+        _wscale_cache[id(weight)] = ent
+    return ent[2]
 
 
 def _scaled_const_noise(noise_const, noise_strength):
@@ -298,6 +311,15 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
+        k = self.weight.shape[-1]
+        if (self.up == 1 and self.down == 1 and k in (1, 3) and self.activation in ('linear', 'lrelu') and use_hip_modconv
+                and _inference_on_gpu(x, self.weight, self.bias) and _modconv_init()):
+            # MI355X inference: conv + bias + activation in ONE launch of the MFMA kernel (csrc/modconv.hip, no modulation)
+            spec = bias_act.activation_funcs[self.activation]
+            act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+            return _modconv_plugin.modconv2d(x.contiguous(), _scaled_weight(self.weight, self.weight_gain), None, None, None, 0.0,
+                                             self.bias, spec.cuda_idx, spec.def_alpha, self.act_gain * gain,
+                                             -1.0 if act_clamp is None else act_clamp)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,

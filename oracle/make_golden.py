@@ -346,6 +346,39 @@ def gen_generator():
     save('generator_tiny', [case])
 
 
+def _sd_fingerprint(module):
+    """Order-sensitive checksum of a state dict (float64): sum(|t|) and sum(t * ramp) per tensor."""
+    out = []
+    for k, v in module.state_dict().items():
+        v = v.double().flatten()
+        out.append([float(v.abs().sum()), float((v * torch.linspace(0.5, 1.5, v.numel(), dtype=torch.float64)).sum())])
+    return torch.tensor(out, dtype=torch.float64)
+
+
+def gen_encoder():
+    """HybridEncoder / Encoder forward (inversion/networks.py:1559-1665).  The weights (tens of MB) are not stored: both
+    sides are built under the same torch seed (parameters are created in the same order), the fixture keeps a
+    fingerprint of the reference state dict so the test can prove the weights are the same before comparing outputs."""
+    cases = []
+    g = torch.Generator().manual_seed(17)
+    torch.manual_seed(1234)
+    E = r_nets.HybridEncoder(size=16, n_latents_app=3, n_latents_geo=2, w_dim=8, add_dim=0, input_img_dim=3, input_seg_dim=19).eval()
+    img = torch.randn(2, 3, 16, 16, generator=g); seg = torch.randn(2, 19, 16, 16, generator=g)
+    with torch.no_grad():
+        out = E(img, seg)
+    cases.append(dict(cfg=dict(fn='hybrid_encoder', seed=1234, size=16, n_latents_app=3, n_latents_geo=2, w_dim=8, add_dim=0,
+                               keys=list(E.state_dict().keys())),
+                      in_img=img, in_seg=seg, out_ws=out, sd_fingerprint=_sd_fingerprint(E)))
+    torch.manual_seed(4321)
+    E1 = r_nets.Encoder(size=8, n_latents=2, w_dim=4, add_dim=2, input_dim=3).eval()
+    x = torch.randn(3, 3, 8, 8, generator=g)
+    with torch.no_grad():
+        ws, extra = E1(x)
+    cases.append(dict(cfg=dict(fn='encoder', seed=4321, size=8, n_latents=2, w_dim=4, add_dim=2, keys=list(E1.state_dict().keys())),
+                      in_x=x, out_ws=ws, out_extra=extra, sd_fingerprint=_sd_fingerprint(E1)))
+    save('encoder', cases)
+
+
 def gen_post():
     """mask2color / layout_grid / create_samples.  dnnlib/seg_tools.py and extract_shapes.py import packages that are
     not installed (torchvision, BiSeNet, mrcfile), so their few-line function bodies are executed here from the
@@ -388,4 +421,5 @@ if __name__ == '__main__':
     gen_triplane()
     gen_networks()
     gen_generator()
+    gen_encoder()
     gen_post()

@@ -214,3 +214,31 @@ def test_hipgraph_replay_equals_eager(golden, gpu_device):
             ws = G.mapping(z, cond)
             img_e, seg_e = G.synthesis(ws, c=cam, noise_mode='const', return_seg=True, ray_jitter=False)
         assert torch.equal(img_g, img_e) and torch.equal(seg_g, seg_e)
+
+
+def test_hybrid_encoder_gpu(golden, gpu_device):
+    """HybridEncoder / Encoder forward on the GPU (stride-1 convs on the MFMA kernel, FIR + bias_act on their HIP kernels):
+    reference-run fixture (small towers) and the CPU oracle at 256x256 inputs with 512-wide latents."""
+    from oracle import encoder as oenc
+    from training import encoders
+    from test_host_cpu import build_encoder
+    for cfg, a in golden('encoder'):
+        E = build_encoder(cfg).to(gpu_device)
+        with torch.no_grad():
+            if cfg['fn'] == 'hybrid_encoder':
+                _rel(E(t(a['in_img'], gpu_device), t(a['in_seg'], gpu_device)), a['out_ws'], 1e-3, 'hybrid encoder vs reference')
+            else:
+                ws, extra = E(t(a['in_x'], gpu_device))
+                _rel(ws, a['out_ws'], 1e-3, 'encoder ws vs reference'); _rel(extra, a['out_extra'], 1e-3, 'encoder extra vs reference')
+    before = _calls('modconv2d')
+    torch.manual_seed(5)
+    E = encoders.HybridEncoder(size=256, n_latents_app=10, n_latents_geo=8, w_dim=512).eval()
+    sd = {k: v.detach().clone() for k, v in E.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    img = torch.randn(1, 3, 256, 256, generator=g).clamp(-1, 1); seg = torch.randn(1, 19, 256, 256, generator=g)
+    with torch.no_grad():
+        got = E.to(gpu_device)(img.to(gpu_device), seg.to(gpu_device))
+    assert got.shape == (1, 18, 512)
+    assert _calls('modconv2d') - before >= 2 * (1 + 6), 'stem + conv1 of every residual block must run on the HIP conv kernel'
+    ref = oenc.hybrid_encoder(sd, img, seg, 10, 8, 512, ops=fast_ops)
+    _rel(got, ref, 1e-3, 'hybrid encoder 256 vs oracle')

@@ -275,6 +275,40 @@ def test_video_sweep_cpu(golden):
     assert got.shape == (8, 4, 6) and np.allclose(got[5], ref_i(5 / 4), atol=1e-6) and np.allclose(got[0], g[0], atol=1e-6)
 
 
+def _fingerprint(module):
+    out = []
+    for k, v in module.state_dict().items():
+        v = v.double().flatten()
+        out.append([float(v.abs().sum()), float((v * torch.linspace(0.5, 1.5, v.numel(), dtype=torch.float64)).sum())])
+    return np.array(out)
+
+
+def build_encoder(cfg):
+    """Encoder of a golden case, built under the case's seed (same parameter creation order as the reference)."""
+    from training import encoders
+    torch.manual_seed(cfg['seed'])
+    if cfg['fn'] == 'hybrid_encoder':
+        return encoders.HybridEncoder(size=cfg['size'], n_latents_app=cfg['n_latents_app'], n_latents_geo=cfg['n_latents_geo'],
+                                      w_dim=cfg['w_dim'], add_dim=cfg['add_dim']).eval()
+    return encoders.Encoder(size=cfg['size'], n_latents=cfg['n_latents'], w_dim=cfg['w_dim'], add_dim=cfg['add_dim']).eval()
+
+
+def test_encoders_cpu(golden):
+    """HybridEncoder / Encoder (inversion/networks.py:1559-1665): same state-dict keys and (seeded) weights as the
+    reference, same outputs as the reference run that produced the fixture."""
+    for cfg, a in golden('encoder'):
+        E = build_encoder(cfg)
+        assert list(E.state_dict().keys()) == cfg['keys']
+        np.testing.assert_allclose(_fingerprint(E), a['sd_fingerprint'], rtol=1e-12, atol=0)
+        with torch.no_grad():
+            if cfg['fn'] == 'hybrid_encoder':
+                assert_close(E(t(a['in_img']), t(a['in_seg'])), a['out_ws'], rtol=1e-4, atol=1e-4, what='hybrid encoder ws')
+            else:
+                ws, extra = E(t(a['in_x']))
+                assert_close(ws, a['out_ws'], rtol=1e-4, atol=1e-4, what='encoder ws')
+                assert_close(extra, a['out_extra'], rtol=1e-4, atol=1e-4, what='encoder extra head')
+
+
 def test_full_spec_shapes():
     from training import triplane
     sp = triplane.GeneratorSpec()
