@@ -35,11 +35,14 @@ namespace ide3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3 };
+enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3, MODE_CONV3S2 = 4 };
 
 template <int MODE> struct ModeCfg;
 template <> struct ModeCfg<MODE_CONV3>  { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 template <> struct ModeCfg<MODE_CONV1>  { static constexpr int KC = 16, WTAPS = 1, MAXT = 1; };
+// 3x3 stride-2 convolution without padding (the conv after the low-pass filter of a down-sampling Conv2dLayer,
+// conv2d_resample.py:100-103): output (h - 3) / 2 + 1; a P x Q output tile reads a (2P + 1) x (2Q + 1) input patch.
+template <> struct ModeCfg<MODE_CONV3S2> { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9, MAXT = 4; };
 // all-class transposed conv: one block computes the four output parity classes of its grid tile from ONE staged input
 // patch and all 9 taps (each tap feeds exactly one class), i.e. 4x the MFMA work per staging step / barrier of mode 2.
@@ -57,10 +60,12 @@ struct McCfg {
     static constexpr int MTW = (BIG == 1) ? 2 : 1;          // 32-row M tiles per wave
     static constexpr int NTW = (BN / 32) / WN;              // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
-    static constexpr int HALO = (MODE == MODE_CONV1) ? 0 : 1;
-    static constexpr int HP = PH + 2 * HALO, HW = PW + 2 * HALO;   // (halo) patch
+    static constexpr int STRIDE = (MODE == MODE_CONV3S2) ? 2 : 1;
+    static constexpr int HALO = (MODE == MODE_CONV1 || MODE == MODE_CONV3S2) ? 0 : 1;
+    static constexpr int HP = (MODE == MODE_CONV3S2) ? 2 * PH + 1 : PH + 2 * HALO;   // (halo) patch
+    static constexpr int HW = (MODE == MODE_CONV3S2) ? 2 * PW + 1 : PW + 2 * HALO;
     // LDS row pitch: with 16-pixel rows a pitch = 16 (mod 32) puts the two pixel rows of an MFMA N tile on disjoint banks
-    static constexpr int XW = (MODE == MODE_CONV1) ? PW : ((PW == 16) ? 48 : HW + 2);
+    static constexpr int XW = (MODE == MODE_CONV1) ? PW : (MODE == MODE_CONV3S2) ? ((HW + 3) & ~3) : ((PW == 16) ? 48 : HW + 2);
     static constexpr int XS = HP * XW;                      // per-channel pitch
     static constexpr int XI = KC * XS;                      // per-image pitch
     static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
@@ -141,7 +146,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 
     // ---- tap table of this block: weight index and patch offsets (dy, dx) ----
     int ntaps, t_widx[K::MAXT], t_off[K::MAXT];
-    if (MODE == MODE_CONV3) {
+    if (MODE == MODE_CONV3 || MODE == MODE_CONV3S2) {
         ntaps = 9;
 #pragma unroll
         for (int t = 0; t < 9; ++t) { t_widx[t] = t; t_off[t] = (t / 3) * K::XW + (t % 3); }
@@ -182,7 +187,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
             const int ry = r % K::HP; r /= K::HP;
             const int cil = r % K::KC; r /= K::KC;
             const int ti = r;
-            const int yy = y0 - K::HALO + ry, xx = x0 - K::HALO + rx;
+            const int yy = y0 * K::STRIDE - K::HALO + ry, xx = x0 * K::STRIDE - K::HALO + rx;
             x_dst[i] = ti * K::XI + cil * K::XS + ry * K::XW + rx;
             x_img[i] = ti * K::KC + cil;                               // (image, channel-in-chunk)
             if (n0 + ti < p.n && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_)
@@ -207,7 +212,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     for (int j = 0; j < K::NTW; ++j) {
         const int pix = (wn * K::NTW + j) * 32 + l32;
         const int ti = pix / (PH * PW), rem = pix % (PH * PW);
-        boff[j] = ti * K::XI + (rem / PW) * K::XW + (rem % PW) + half * K::XS;
+        boff[j] = ti * K::XI + (rem / PW) * K::STRIDE * K::XW + (rem % PW) * K::STRIDE + half * K::XS;
     }
     const int aoff = half * K::BM + wm * K::MTW * 32 + l32;
 
@@ -368,15 +373,15 @@ struct ConvPlan {
 };
 
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
-    pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
+    pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !getenv("IDE3D_MODCONV_NO_TCONV3A");
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
     const bool transposed = (pl.mode == MODE_TCONV3 || pl.mode == MODE_TCONV3A);
-    pl.oh = transposed ? 2 * p.h + 1 : p.h;
-    pl.ow = transposed ? 2 * p.w_ + 1 : p.w_;
+    pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
+    pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     // class grids
     int gh[4], gw[4];
@@ -384,16 +389,17 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     for (int c = 0; c < 4; ++c) {
         if (pl.mode == MODE_TCONV3) { gh[c] = (c >> 1) ? p.h : p.h + 1; gw[c] = (c & 1) ? p.w_ : p.w_ + 1; }
         else if (pl.mode == MODE_TCONV3A) { gh[c] = p.h + 1; gw[c] = p.w_ + 1; }
+        else if (pl.mode == MODE_CONV3S2) { gh[c] = pl.oh; gw[c] = pl.ow; }
         else { gh[c] = p.h; gw[c] = p.w_; }
     }
-    const int mind = (p.h < p.w_) ? p.h : p.w_;
+    const int mind = (pl.mode == MODE_CONV3S2) ? ((pl.oh < pl.ow) ? pl.oh : pl.ow) : ((p.h < p.w_) ? p.h : p.w_);
     pl.tile = (mind >= 12 || p.w_batch_stride) ? 0 : (mind >= 6 ? 1 : 2);     // per-image weights need one image per tile
     // 256-pixel tiles (8 accumulators per wave) for big-cout 3x3 layers with enough work to fill the chip twice over
-    if (pl.tile == 0 && pl.big == 1 && pl.mode != MODE_CONV1 && !p.w_batch_stride) {
+    if (pl.tile == 0 && pl.big == 1 && pl.mode != MODE_CONV1 && pl.mode != MODE_CONV3S2 && !p.w_batch_stride) {
         const int64_t blocks256 = (int64_t)pl.mblocks * cdiv(gh[0], 16) * cdiv(gw[0], 16) * p.n * ((pl.mode == MODE_TCONV3) ? 4 : 1);
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
-    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1)) ? 0 : t; }
+    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
     if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
     static const int TIv[5] = {1, 2, 8, 1, 1}, PHv[5] = {8, 8, 4, 16, 4}, PWv[5] = {16, 8, 4, 16, 16};
     ConvGeom& g = pl.g;
@@ -429,7 +435,7 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     if (pl.tile == 0)      hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
-    else if constexpr (BIG == 1 && MODE != MODE_CONV1)
+    else if constexpr (BIG == 1 && MODE != MODE_CONV1 && MODE != MODE_CONV3S2)
         hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
 }
 
@@ -439,7 +445,9 @@ static int check_modconv(const ide3d_modconv_params& p) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(p.n > 0 && p.cin > 0 && p.cout > 0 && p.h > 0 && p.w_ > 0, "modconv2d: bad shape");
     IDE3D_CHECK_ARG(p.k == 1 || p.k == 3, "modconv2d: kernel size must be 1 or 3 (got %d)", p.k);
-    IDE3D_CHECK_ARG(p.mode == 0 || (p.mode == 2 && p.k == 3), "modconv2d: mode must be 0 (conv) or 2 (3x3 transposed, stride 2)");
+    IDE3D_CHECK_ARG(p.mode == 0 || ((p.mode == 1 || p.mode == 2) && p.k == 3),
+                    "modconv2d: mode must be 0 (conv), 1 (3x3 stride-2 conv, no padding) or 2 (3x3 transposed, stride 2)");
+    IDE3D_CHECK_ARG(p.mode != 1 || (p.h >= 3 && p.w_ >= 3), "modconv2d: stride-2 convolution needs an input of at least 3x3");
     IDE3D_CHECK_ARG((int64_t)p.n * p.cin * p.h * p.w_ < 0x7fffffffLL, "modconv2d: input too large for 32-bit indexing");
     return IDE3D_OK;
 }
@@ -477,6 +485,7 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
          else launch_tiles<M, 0>(p, pl, wp, partial, st); } while (0)
     if (pl.mode == MODE_CONV3)       IDE3D_MC_DISPATCH(MODE_CONV3);
     else if (pl.mode == MODE_CONV1)  IDE3D_MC_DISPATCH(MODE_CONV1);
+    else if (pl.mode == MODE_CONV3S2) IDE3D_MC_DISPATCH(MODE_CONV3S2);
     else if (pl.mode == MODE_TCONV3A) IDE3D_MC_DISPATCH(MODE_TCONV3A);
     else                             IDE3D_MC_DISPATCH(MODE_TCONV3);
 #undef IDE3D_MC_DISPATCH

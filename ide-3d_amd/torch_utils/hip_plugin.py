@@ -642,8 +642,9 @@ class ModconvPlugin:
 
     @staticmethod
     def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0):
-        """mode 0: stride-1 k x k modulated conv with fused epilogue; mode 2: 3x3 transposed stride-2 conv
-        (output (2h+1) x (2w+1), demodulation applied, no noise / bias / activation unless given)."""
+        """mode 0: stride-1 k x k (modulated) conv, "same" padding, fused epilogue; mode 1: 3x3 stride-2 conv without padding
+        (output ((h-3)//2+1) x ((w-3)//2+1)); mode 2: 3x3 transposed stride-2 conv (output (2h+1) x (2w+1)).
+        styles / dcoefs / noise / bias may be None."""
         for t in (x, w):
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'modconv2d: contiguous float32 CUDA tensors required')
         n, cin, h, wd = x.shape
@@ -652,8 +653,9 @@ class ModconvPlugin:
             _require(w.shape[0] == n and styles is None, 'modconv2d: per-image weights need w.shape[0] == batch and styles=None')
         cout, cin2, k, k2 = w.shape[-4:]
         _require(cin == cin2 and k == k2 and k in (1, 3), 'modconv2d: weight must be [cout, cin, k, k] with k in {1, 3}')
-        _require(mode in (0, 2), 'modconv2d: mode must be 0 or 2')
-        oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (h, wd)
+        _require(mode in (0, 1, 2), 'modconv2d: mode must be 0, 1 or 2')
+        _require(mode != 1 or (k == 3 and h >= 3 and wd >= 3), 'modconv2d: mode 1 is a 3x3 stride-2 convolution on an input of at least 3x3')
+        oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (((h - 3) // 2 + 1, (wd - 3) // 2 + 1) if mode == 1 else (h, wd))
         y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
         lib = load()
         key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index)

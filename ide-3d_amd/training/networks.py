@@ -320,6 +320,23 @@ class Conv2dLayer(torch.nn.Module):
             return _modconv_plugin.modconv2d(x.contiguous(), _scaled_weight(self.weight, self.weight_gain), None, None, None, 0.0,
                                              self.bias, spec.cuda_idx, spec.def_alpha, self.act_gain * gain,
                                              -1.0 if act_clamp is None else act_clamp)
+        if (self.up == 1 and self.down == 2 and k in (1, 3) and self.activation in ('linear', 'lrelu') and use_hip_modconv
+                and self.resample_filter.ndim == 2 and _inference_on_gpu(x, self.weight, self.bias) and _modconv_init()):
+            # down-sampling layer, same decomposition as conv2d_resample.py:73-78,95-103: k = 1 -> FIR + decimation, then the
+            # 1x1 conv at low resolution; k = 3 -> FIR at full resolution, then the stride-2 conv (mode 1 of the MFMA kernel)
+            spec = bias_act.activation_funcs[self.activation]
+            act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+            fw = self.resample_filter.shape[-1]
+            p0, p1 = self.padding + (fw - self.down + 1) // 2, self.padding + (fw - self.down) // 2
+            if k == 1:
+                y = upfirdn2d.upfirdn2d(x, self.resample_filter, down=2, padding=[p0, p1, p0, p1])
+                mode = 0
+            else:
+                y = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[p0, p1, p0, p1])
+                mode = 1
+            return _modconv_plugin.modconv2d(y.contiguous(), _scaled_weight(self.weight, self.weight_gain), None, None, None, 0.0,
+                                             self.bias, spec.cuda_idx, spec.def_alpha, self.act_gain * gain,
+                                             -1.0 if act_clamp is None else act_clamp, mode=mode)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,

@@ -323,6 +323,9 @@ typedef struct ide3d_modconv_params {
     float noise_strength;
     int32_t act; float alpha, gain, clamp;
     int32_t mode;             /* 0: stride-1 k x k "same" correlation (y is h x w);
+                                 1: 3x3 correlation, stride 2, no padding (y is ((h-3)/2+1) x ((w-3)/2+1)) — the conv that
+                                    follows the low-pass filter of a down-sampling Conv2dLayer (conv2d_resample.py:100-103;
+                                    styles / dcoefs may be NULL: plain convolution, inversion/networks.py:169-226);
                                  2: 3x3 transposed convolution, stride 2, pad 0 (y is (2h+1) x (2w+1)) —
                                     `conv_transpose2d(x, w.transpose(0,1), stride=2)` of conv2d_resample.py:114-125 */
     int32_t weights_packed;   /* 1: `workspace` already holds the packed form of `w` from an earlier call */

@@ -529,3 +529,21 @@ def test_modconv2d_packed_weight_cache_is_identity_safe(gpu_device):
         if w2.data_ptr() == ptr:
             break
     assert_close(run(w2), ref(w2).cpu(), rtol=1e-4, atol=1e-4, what='new weight (possibly at the recycled address)')
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 16, 32, 19, 23), (1, 64, 128, 65, 65), (4, 8, 40, 7, 9), (3, 32, 64, 4, 3), (1, 512, 512, 17, 17)])
+def test_modconv2d_stride2_against_conv2d(gpu_device, n, cin, cout, h, w):
+    """mode 1: 3x3 stride-2 convolution without padding + bias + lrelu == F.conv2d (fp64), plain (styles / dcoefs NULL) and modulated."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(n, cin, h, w, generator=g).to(gpu_device)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(gpu_device)
+    b = torch.randn(cout, generator=g).to(gpu_device)
+    got = hip_plugin.ModconvPlugin.modconv2d(x, wt, None, None, None, 0.0, b, 3, 0.2, math.sqrt(2), -1.0, mode=1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double().cpu(), wt.double().cpu(), b.double().cpu(), stride=2), 0.2) * math.sqrt(2)
+    assert got.shape == ref.shape
+    assert_close(got, ref.float(), rtol=2e-4, atol=2e-4, what='stride-2 conv')
+    s = (torch.randn(n, cin, generator=g) + 1).to(gpu_device); d = torch.rand(n, cout, generator=g).to(gpu_device)
+    got = hip_plugin.ModconvPlugin.modconv2d(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=1)
+    ref = torch.nn.functional.conv2d((x.double() * s.double()[:, :, None, None]).cpu(), wt.double().cpu(), stride=2) * d.double().cpu()[:, :, None, None]
+    assert_close(got, ref.float(), rtol=2e-4, atol=2e-4, what='modulated stride-2 conv')

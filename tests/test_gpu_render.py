@@ -239,6 +239,6 @@ def test_hybrid_encoder_gpu(golden, gpu_device):
     with torch.no_grad():
         got = E.to(gpu_device)(img.to(gpu_device), seg.to(gpu_device))
     assert got.shape == (1, 18, 512)
-    assert _calls('modconv2d') - before >= 2 * (1 + 6), 'stem + conv1 of every residual block must run on the HIP conv kernel'
+    assert _calls('modconv2d') - before == 2 * (1 + 3 * 6), 'every Conv2dLayer of both towers must run on the HIP conv kernel'
     ref = oenc.hybrid_encoder(sd, img, seg, 10, 8, 512, ops=fast_ops)
     _rel(got, ref, 1e-3, 'hybrid encoder 256 vs oracle')
