@@ -52,4 +52,7 @@ def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU visible')
+    from torch_utils import custom_ops, hip_plugin
+    if not os.path.isfile(hip_plugin.lib_path()):      # normally built by __graft_entry__.build() and shipped in-tree
+        custom_ops.build_library(verbose=False)
     return torch.device('cuda:0')
