@@ -8,8 +8,14 @@ using the reference's fp32 arithmetic operation by operation (including its floa
 "indices" are not floored, extract_shapes.py:84-86).  With 288 GB of HBM the whole 256^3 cube is one launch
 (`max_batch=None`).
 
-Marching cubes / .mrc / .ply writers (extract_shapes.py:27-70,195-219) are host-side consumers of the cube: out of scope.
+`save_density_cube` writes the two files of extract_shapes.py:191-194 — `<name>.npy` and an MRC2014 volume
+(`mrcfile.new_mmap(..., mrc_mode=2)` there; here a dependency-free writer of the same 1024-byte header + float32
+voxels, since `mrcfile` is not installed).  Marching cubes / .ply export (extract_shapes.py:27-70,195-219) is a further
+host-side consumer of the cube: out of scope.
 """
+
+import os
+import struct
 
 import numpy as np
 import torch
@@ -109,3 +115,48 @@ def sample_generator_ide3d(generator, aux_img_net, z, c, max_batch=100000, voxel
                            voxel_origin=voxel_origin, cube_length=cube_length)
     sig = sig.reshape(voxel_resolution, voxel_resolution, voxel_resolution)
     return sig.cpu().numpy() if to_numpy else sig
+
+
+def write_mrc(path, volume: np.ndarray):
+    """MRC2014 file, mode 2 (float32), axis order (sections, rows, columns) = volume.shape like `mrcfile` writes it:
+    nx = shape[2] (fastest), ny = shape[1], nz = shape[0]; cell 0 / sampling equal to the grid (what mrcfile.new_mmap
+    leaves when only `data` is assigned, extract_shapes.py:191-192); header statistics filled in."""
+    v = np.ascontiguousarray(volume, dtype=np.float32)
+    assert v.ndim == 3
+    nz, ny, nx = v.shape
+    h = bytearray(1024)
+    struct.pack_into('<3i', h, 0, nx, ny, nz)                 # NX NY NZ
+    struct.pack_into('<i', h, 12, 2)                          # MODE 2 = float32
+    struct.pack_into('<3i', h, 16, 0, 0, 0)                   # NXSTART NYSTART NZSTART
+    struct.pack_into('<3i', h, 28, nx, ny, nz)                # MX MY MZ
+    struct.pack_into('<3f', h, 40, 0.0, 0.0, 0.0)             # CELLA (unset)
+    struct.pack_into('<3f', h, 52, 90.0, 90.0, 90.0)          # CELLB
+    struct.pack_into('<3i', h, 64, 1, 2, 3)                   # MAPC MAPR MAPS
+    struct.pack_into('<3f', h, 76, float(v.min()), float(v.max()), float(v.mean(dtype=np.float64)))   # DMIN DMAX DMEAN
+    struct.pack_into('<i', h, 88, 1)                          # ISPG: 1 = volume
+    struct.pack_into('<i', h, 92, 0)                          # NSYMBT
+    h[104:108] = b'\x00\x00\x00\x00'                          # EXTTYP
+    struct.pack_into('<i', h, 108, 20140)                     # NVERSION
+    h[208:212] = b'MAP '
+    h[212:216] = bytes([0x44, 0x44, 0x00, 0x00])              # little-endian machine stamp
+    struct.pack_into('<f', h, 216, float(v.std(dtype=np.float64)))   # RMS
+    struct.pack_into('<i', h, 220, 0)                         # NLABL
+    with open(path, 'wb') as f:
+        f.write(bytes(h))
+        f.write(v.tobytes())
+
+
+def read_mrc(path) -> np.ndarray:
+    """Inverse of `write_mrc` for mode-2 files without extended header (used by the tests)."""
+    with open(path, 'rb') as f:
+        h = f.read(1024)
+        nx, ny, nz, mode = struct.unpack_from('<4i', h, 0)
+        assert mode == 2 and h[208:212] == b'MAP ' and struct.unpack_from('<i', h, 92)[0] == 0
+        return np.frombuffer(f.read(), dtype='<f4').reshape(nz, ny, nx)
+
+
+def save_density_cube(outdir, name, voxel_grid: np.ndarray):
+    """extract_shapes.py:191-194: `<name>.mrc` + `<name>.npy`."""
+    os.makedirs(outdir, exist_ok=True)
+    write_mrc(os.path.join(outdir, f'{name}.mrc'), voxel_grid)
+    np.save(os.path.join(outdir, f'{name}.npy'), voxel_grid)

@@ -235,6 +235,23 @@ def test_shape_extraction_cpu(golden):
     assert np.array_equal(one, cube)
 
 
+def test_density_cube_files(tmp_path):
+    """`.npy` + MRC2014 (mode 2) sinks of extract_shapes.py:191-194: header fields and voxel round trip."""
+    import struct
+    from training import shape_extraction as se
+    v = np.random.RandomState(3).randn(5, 6, 7).astype(np.float32)
+    se.save_density_cube(str(tmp_path), '17', v)
+    assert np.array_equal(np.load(tmp_path / '17.npy'), v)
+    raw = (tmp_path / '17.mrc').read_bytes()
+    assert len(raw) == 1024 + v.nbytes
+    nx, ny, nz, mode = struct.unpack_from('<4i', raw, 0)
+    assert (nx, ny, nz, mode) == (7, 6, 5, 2) and struct.unpack_from('<3i', raw, 64) == (1, 2, 3)
+    assert raw[208:212] == b'MAP ' and struct.unpack_from('<i', raw, 108)[0] == 20140
+    dmin, dmax, dmean = struct.unpack_from('<3f', raw, 76)
+    assert np.isclose(dmin, v.min()) and np.isclose(dmax, v.max()) and np.isclose(dmean, v.mean(), atol=1e-6)
+    assert np.array_equal(se.read_mrc(tmp_path / '17.mrc'), v)
+
+
 def test_video_sweep_cpu(golden):
     """gen_videos.py frame loop (training.video_render): batched cells + cached tri-planes == the reference's schedule
     rendered cell by cell (batch 1, no caching), camera sweep == direct LookAtPoseSampler calls, ws interpolation == scipy."""
