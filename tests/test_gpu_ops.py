@@ -547,3 +547,76 @@ def test_modconv2d_stride2_against_conv2d(gpu_device, n, cin, cout, h, w):
     got = hip_plugin.ModconvPlugin.modconv2d(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=1)
     ref = torch.nn.functional.conv2d((x.double() * s.double()[:, :, None, None]).cpu(), wt.double().cpu(), stride=2) * d.double().cpu()[:, :, None, None]
     assert_close(got, ref.float(), rtol=2e-4, atol=2e-4, what='modulated stride-2 conv')
+
+
+# ---- gradfix surfaces (custom autograd graphs; only active on device tensors with the module switch on) -----------------
+
+def test_conv2d_gradfix_second_order(gpu_device):
+    """conv2d_gradfix with `enabled`: outputs, first- and second-order gradients (R1-style: grad of |dy/dx|^2 w.r.t. the
+    weight) equal plain autograd through torch.nn.functional; `no_weight_gradients` suppresses the weight gradient."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(71)
+    cases = [(False, dict(stride=1, padding=1)), (False, dict(stride=2, padding=1)), (True, dict(stride=2, padding=0)),
+             (False, dict(stride=1, padding=0, groups=2))]
+    for transpose, kw in cases:
+        groups = kw.get('groups', 1)
+        x0 = torch.randn(2, 4, 9, 10, generator=g).double().to(gpu_device)
+        w0 = (torch.randn(4, 4 // groups, 3, 3, generator=g) if not transpose else torch.randn(4, 6, 3, 3, generator=g)).double().to(gpu_device)
+        res = []
+        for use_custom in (True, False):
+            cg.enabled = use_custom
+            try:
+                x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+                fn = cg.conv_transpose2d if transpose else cg.conv2d
+                y = fn(x, w, **kw)
+                (gx,) = torch.autograd.grad(y.square().sum(), [x], create_graph=True)
+                pen = gx.square().sum()
+                gw, gx2 = torch.autograd.grad(pen, [w, x])
+                res.append((y.detach(), gx.detach(), gw, gx2))
+            finally:
+                cg.enabled = False
+        for a, b, name in zip(res[0], res[1], ('y', 'dx', 'd(pen)/dw', 'd(pen)/dx')):
+            assert_close(a, b.cpu(), rtol=1e-9, atol=1e-9, what=f'{name} transpose={transpose} {kw}')
+    cg.enabled = True
+    try:
+        x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+        with cg.no_weight_gradients():
+            y = cg.conv_transpose2d(x, w, stride=2) if transpose else cg.conv2d(x, w, **kw)
+            gx, gw = torch.autograd.grad(y.sum(), [x, w], allow_unused=True)
+        assert gw is None and gx is not None and not cg.weight_gradients_disabled
+    finally:
+        cg.enabled = False
+
+
+def test_grid_sample_gradfix_second_order(gpu_device):
+    """grid_sample_gradfix with `enabled`: value and first-order gradients equal plain autograd through F.grid_sample;
+    the second-order path (which plain autograd does not have) satisfies the analytic identity
+    d/dp |A^T p|^2 = 2 A A^T p for the linear look-up A = sample(., grid)."""
+    from torch_utils.ops import grid_sample_gradfix as gs
+    g = torch.Generator().manual_seed(72)
+    img0 = torch.randn(2, 3, 7, 9, generator=g).double().to(gpu_device)
+    grid0 = (torch.rand(2, 5, 6, 2, generator=g) * 2.2 - 1.1).double().to(gpu_device)
+    wgt = torch.randn(2, 3, 5, 6, generator=g).double().to(gpu_device)
+    res = []
+    for use_custom in (True, False):
+        gs.enabled = use_custom
+        try:
+            img = img0.clone().requires_grad_(True); grid = grid0.clone().requires_grad_(True)
+            y = gs.grid_sample(img, grid)
+            d_img, d_grid = torch.autograd.grad((y * wgt).sum(), [img, grid])
+            res.append((y.detach(), d_img, d_grid))
+        finally:
+            gs.enabled = False
+    for a_, b_, name in zip(res[0], res[1], ('y', 'd image', 'd grid')):
+        assert_close(a_, b_.cpu(), rtol=1e-9, atol=1e-9, what=name)
+    gs.enabled = True
+    try:
+        img = img0.clone().requires_grad_(True)
+        probe = wgt.clone().requires_grad_(True)
+        y = gs.grid_sample(img, grid0)
+        (d_img,) = torch.autograd.grad((y * probe).sum(), [img], create_graph=True)       # A^T p
+        (d_probe,) = torch.autograd.grad(d_img.square().sum(), [probe])
+    finally:
+        gs.enabled = False
+    expect = 2 * torch.nn.functional.grid_sample(d_img.detach(), grid0, mode='bilinear', padding_mode='zeros', align_corners=False)
+    assert_close(d_probe, expect.cpu(), rtol=1e-9, atol=1e-9, what='second order')
