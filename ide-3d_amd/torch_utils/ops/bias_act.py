@@ -6,6 +6,8 @@ the reference dispatches (bias_act.py:84-86).  A missing / broken HIP library is
 device tensors — there is no silent fallback.
 """
 
+import collections
+
 import numpy as np
 import torch
 
@@ -57,7 +59,8 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
-        return _bias_act_cuda(dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp).apply(x, b)
+        spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+        return _BiasActHip.apply(x, b, _Call(dim, act, alpha, gain, clamp))
     return _bias_act_ref(x=x, b=b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 
@@ -81,70 +84,74 @@ def _bias_act_ref(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=N
     return y
 
 
-_bias_act_cuda_cache = dict()
+# ---- device path: `ide3d_bias_act` evaluates the op (grad = 0), its derivative applied to dy (grad = 1) and the second
+# derivative term (grad = 2); the autograd functions below only decide which tensors each order needs to keep. ----------
+
+_Call = collections.namedtuple('_Call', 'dim act alpha gain clamp')      # resolved, hashable parameters of one call
 
 
-def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
-    """autograd.Function bound to one (dim, act, alpha, gain, clamp) tuple; cached like bias_act.py:124-139."""
-    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
-    key = (dim, act, alpha, gain, clamp)
-    if key in _bias_act_cuda_cache:
-        return _bias_act_cuda_cache[key]
+def _layout(t):
+    return torch.channels_last if (t.ndim > 2 and t.stride(1) == 1) else torch.contiguous_format
 
-    trivial = (act == 'linear' and gain == 1 and clamp < 0)
-    keep_x = ('x' in spec.ref) or spec.has_2nd_grad
-    keep_y = 'y' in spec.ref
 
-    def layout_of(t):
-        return torch.channels_last if (t.ndim > 2 and t.stride(1) == 1) else torch.contiguous_format
+def _is_identity(call):
+    return call.act == 'linear' and call.gain == 1 and call.clamp < 0
 
-    def null_like(_t):
-        return _null_tensor
 
-    class BiasActCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, b):
-            ctx.memory_format = layout_of(x)
-            x = x.contiguous(memory_format=ctx.memory_format)
-            b = b.contiguous() if b is not None else null_like(x)
-            y = x
-            if not trivial or b.numel():
-                nul = null_like(x)
-                y = _plugin.bias_act(x, b, nul, nul, nul, 0, dim, spec.cuda_idx, alpha, gain, clamp)
-            ctx.save_for_backward(x if keep_x else null_like(x), b if keep_x else null_like(x), y if keep_y else null_like(x))
-            return y
+def _launch(call, grad, x, b, xref, yref, dy):
+    return _plugin.bias_act(x, b, xref, yref, dy, grad, call.dim, activation_funcs[call.act].cuda_idx, call.alpha, call.gain, call.clamp)
 
-        @staticmethod
-        def backward(ctx, dy):
-            dy = dy.contiguous(memory_format=ctx.memory_format)
-            x, b, y = ctx.saved_tensors
-            dx = db = None
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dx = dy if trivial else BiasActCudaGrad.apply(dy, x, b, y)
+
+def _sum_to_bias(t, dim):
+    return t.sum([i for i in range(t.ndim) if i != dim])
+
+
+class _BiasActHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, call):
+        spec = activation_funcs[call.act]
+        ctx.call, ctx.layout = call, _layout(x)
+        x = x.contiguous(memory_format=ctx.layout)
+        b = _null_tensor if b is None else b.contiguous()
+        y = x if (_is_identity(call) and not b.numel()) else _launch(call, 0, x, b, _null_tensor, _null_tensor, _null_tensor)
+        wants_x = ('x' in spec.ref) or spec.has_2nd_grad        # what the derivative is expressed in
+        ctx.save_for_backward(x if wants_x else _null_tensor, b if wants_x else _null_tensor, y if 'y' in spec.ref else _null_tensor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, b, y = ctx.saved_tensors
+        call = ctx.call
+        dx = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dy = dy.contiguous(memory_format=ctx.layout)
+            dx = dy if _is_identity(call) else _BiasActHipGrad.apply(dy, x, b, y, call)
             if ctx.needs_input_grad[1]:
-                db = dx.sum([i for i in range(dx.ndim) if i != dim])
-            return dx, db
+                db = _sum_to_bias(dx, call.dim)
+        return dx, db, None
 
-    class BiasActCudaGrad(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, dy, x, b, y):
-            ctx.memory_format = layout_of(dy)
-            dx = _plugin.bias_act(dy, b, x, y, null_like(dy), 1, dim, spec.cuda_idx, alpha, gain, clamp)
-            ctx.save_for_backward(dy if spec.has_2nd_grad else null_like(dy), x, b, y)
-            return dx
 
-        @staticmethod
-        def backward(ctx, d_dx):
-            d_dx = d_dx.contiguous(memory_format=ctx.memory_format)
-            dy, x, b, y = ctx.saved_tensors
-            d_dy = d_x = d_b = None
-            if ctx.needs_input_grad[0]:
-                d_dy = BiasActCudaGrad.apply(d_dx, x, b, y)
-            if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-                d_x = _plugin.bias_act(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
-            if spec.has_2nd_grad and ctx.needs_input_grad[2]:
-                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
-            return d_dy, d_x, d_b, None
+class _BiasActHipGrad(torch.autograd.Function):
+    """dx = dy * act'(.) * gain (zero where clamped); differentiable in dy always, in x / b for the smooth activations."""
 
-    _bias_act_cuda_cache[key] = BiasActCuda
-    return BiasActCuda
+    @staticmethod
+    def forward(ctx, dy, x, b, y, call):
+        ctx.call, ctx.layout = call, _layout(dy)
+        smooth = activation_funcs[call.act].has_2nd_grad
+        ctx.save_for_backward(dy if smooth else _null_tensor, x, b, y)
+        return _launch(call, 1, dy, b, x, y, _null_tensor)
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        dy, x, b, y = ctx.saved_tensors
+        call = ctx.call
+        smooth = activation_funcs[call.act].has_2nd_grad
+        d_dx = d_dx.contiguous(memory_format=ctx.layout)
+        d_dy = d_x = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _BiasActHipGrad.apply(d_dx, x, b, y, call)
+        if smooth and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_x = _launch(call, 2, d_dx, b, x, y, dy)
+            if ctx.needs_input_grad[2]:
+                d_b = _sum_to_bias(d_x, call.dim)
+        return d_dy, d_x, d_b, None, None

@@ -6,6 +6,8 @@ Public names, argument meaning and defaults follow the reference: `setup_filter`
 run `csrc/upfirdn2d.hip` through the C ABI; CPU tensors or `impl='ref'` run the PyTorch definition.
 """
 
+import collections
+
 import numpy as np
 import torch
 
@@ -23,36 +25,37 @@ def _init():
     return True
 
 
+def _int_pair(v, what):
+    vals = [v, v] if isinstance(v, int) else list(v)
+    assert len(vals) == 2 and all(isinstance(e, int) for e in vals), f'{what} must be an int or a pair of ints'
+    return vals
+
+
 def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    assert isinstance(scaling, (list, tuple))
-    assert all(isinstance(v, int) for v in scaling)
-    sx, sy = scaling
-    assert sx >= 1 and sy >= 1
+    """int | [sx, sy] -> (sx, sy), both >= 1."""
+    sx, sy = _int_pair(scaling, 'scaling')
+    assert min(sx, sy) >= 1
     return sx, sy
 
 
 def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(v, int) for v in padding)
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    padx0, padx1, pady0, pady1 = padding
-    return padx0, padx1, pady0, pady1
+    """int | [px, py] | [px0, px1, py0, py1] -> (px0, px1, py0, py1); negative values crop."""
+    vals = [padding] * 2 if isinstance(padding, int) else list(padding)
+    assert all(isinstance(e, int) for e in vals) and len(vals) in (2, 4), 'padding must be an int, a pair or four ints'
+    if len(vals) == 2:
+        vals = [vals[0], vals[0], vals[1], vals[1]]
+    return tuple(vals)
 
 
 def _get_filter_size(f):
+    """(width, height) of a filter; None counts as 1 x 1, a 1-D filter is separable (same taps on both axes)."""
     if f is None:
         return 1, 1
-    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
     with misc.suppress_tracer_warnings():
         fw, fh = int(f.shape[-1]), int(f.shape[0])
     misc.assert_shape(f, [fh, fw][:f.ndim])
-    assert fw >= 1 and fh >= 1
+    assert min(fw, fh) >= 1
     return fw, fh
 
 
@@ -86,7 +89,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
-        return _upfirdn2d_cuda(up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain).apply(x, f)
+        return _Upfirdn2dHip.apply(x, f, _Resample(*_parse_scaling(up), *_parse_scaling(down), *_parse_padding(padding), bool(flip_filter), gain))
     return _upfirdn2d_ref(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
 
 
@@ -123,57 +126,46 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     return u[:, :, ::downy, ::downx]
 
 
-_upfirdn2d_cuda_cache = dict()
+# resolved parameters of one device call (hashable; handed to the autograd function as a plain argument)
+_Resample = collections.namedtuple('_Resample', 'upx upy downx downy px0 px1 py0 py1 flip gain')
 
 
-def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
-    """autograd.Function for one parameter tuple; the backward pass is the op with up/down swapped
-    (reference upfirdn2d.py:250-269)."""
-    upx, upy = _parse_scaling(up)
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    key = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
-    if key in _upfirdn2d_cuda_cache:
-        return _upfirdn2d_cuda_cache[key]
+class _Upfirdn2dHip(torch.autograd.Function):
+    """`ide3d_upfirdn2d` forward; the adjoint of "upsample, pad, filter, decimate" is the same pipeline with the two
+    factors exchanged, the filter mirrored and the padding chosen so that the input size comes back (reference :250-269)."""
 
-    class Upfirdn2dCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, f):
-            assert isinstance(x, torch.Tensor) and x.ndim == 4
-            if f is None:
-                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if f.ndim == 1 and f.shape[0] == 1:
-                f = f.square().unsqueeze(0)      # separable 1-tap == full 1x1
-            assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-            if f.ndim == 2:
-                y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
-            else:   # separable: horizontal pass, then vertical pass carrying the gain
-                y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, 1.0)
-                y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, gain)
-            ctx.save_for_backward(f)
-            ctx.x_shape = x.shape
-            return y
+    @staticmethod
+    def forward(ctx, x, f, r):
+        assert isinstance(x, torch.Tensor) and x.ndim == 4
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        elif f.ndim == 1 and f.shape[0] == 1:
+            f = f.square().unsqueeze(0)           # a 1-tap separable filter is the 1x1 filter with the squared tap
+        assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
+        if f.ndim == 2:
+            y = _plugin.upfirdn2d(x, f, r.upx, r.upy, r.downx, r.downy, r.px0, r.px1, r.py0, r.py1, r.flip, r.gain)
+        else:
+            # separable taps: rows first, then columns (the gain rides on the second pass)
+            y = _plugin.upfirdn2d(x, f.unsqueeze(0), r.upx, 1, r.downx, 1, r.px0, r.px1, 0, 0, r.flip, 1.0)
+            y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, r.upy, 1, r.downy, 0, 0, r.py0, r.py1, r.flip, r.gain)
+        ctx.save_for_backward(f)
+        ctx.r, ctx.in_hw = r, (x.shape[2], x.shape[3])
+        return y
 
-        @staticmethod
-        def backward(ctx, dy):
-            f, = ctx.saved_tensors
-            _, _, ih, iw = ctx.x_shape
-            _, _, oh, ow = dy.shape
-            fw, fh = _get_filter_size(f)
-            p = [
-                fw - padx0 - 1,
-                iw * upx - ow * downx + padx0 - upx + 1,
-                fh - pady0 - 1,
-                ih * upy - oh * downy + pady0 - upy + 1,
-            ]
-            dx = None
-            if ctx.needs_input_grad[0]:
-                dx = _upfirdn2d_cuda(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
-            assert not ctx.needs_input_grad[1]
-            return dx, None
-
-    _upfirdn2d_cuda_cache[key] = Upfirdn2dCuda
-    return Upfirdn2dCuda
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError('upfirdn2d: the filter is not differentiable')
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        (f,) = ctx.saved_tensors
+        r, (ih, iw) = ctx.r, ctx.in_hw
+        fw, fh = _get_filter_size(f)
+        back = _Resample(upx=r.downx, upy=r.downy, downx=r.upx, downy=r.upy,
+                         px0=fw - r.px0 - 1, px1=iw * r.upx - dy.shape[3] * r.downx + r.px0 - r.upx + 1,
+                         py0=fh - r.py0 - 1, py1=ih * r.upy - dy.shape[2] * r.downy + r.py0 - r.upy + 1,
+                         flip=not r.flip, gain=r.gain)
+        return _Upfirdn2dHip.apply(dy, f, back), None, None
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
