@@ -11,7 +11,7 @@ print('avg launch us', r['avg_launch_us'])
 buf = (ctypes.c_ulonglong * 256)()
 assert hip_plugin.load().ide3d_debug_tt(buf) == 0
 v = list(buf)
-print('chunk: [reduce, barrier1, table+loads, taps+lds writes, barrier2, next taps, blend]')
+print('chunk: cycles of [bbox reduce, barrier 1, region table, tap table + region fetch + LDS fill, barrier 2, blend]')
 for ch in range(24):
     row = v[ch * 8:ch * 8 + 7]
     if row[0]:
