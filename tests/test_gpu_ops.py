@@ -620,3 +620,22 @@ def test_grid_sample_gradfix_second_order(gpu_device):
         gs.enabled = False
     expect = 2 * torch.nn.functional.grid_sample(d_img.detach(), grid0, mode='bilinear', padding_mode='zeros', align_corners=False)
     assert_close(d_probe, expect.cpu(), rtol=1e-9, atol=1e-9, what='second order')
+
+
+def test_triplane_image_groups_beyond_2gib(gpu_device):
+    """Planes larger than 2 GiB in total: both gather kernels address images in groups whose byte offsets fit 32 bits
+    (6 images x 403 MB -> groups of 5 + 1); flat == tiled, and a subset equals the oracle (last image included)."""
+    from dnnlib import util
+    n, C, H = 6, 32, 1024
+    g = torch.Generator(device=gpu_device).manual_seed(81)
+    planes = torch.randn(n, 3 * C, H, H, generator=g, device=gpu_device).contiguous(memory_format=torch.channels_last)
+    assert planes.numel() * 4 > 2 ** 31
+    co = (torch.rand(n, 16 * 16 * 8, 3, generator=g, device=gpu_device) * 2 - 1) * 0.9
+    flat = util.sample_from_triplane(co, planes)
+    tiled = util.sample_from_triplane(co, planes, ray_grid=(16, 16, 8))
+    assert torch.equal(flat, tiled)
+    idx = torch.arange(0, co.shape[1], 37, device=gpu_device)
+    for img in (0, 4, 5):
+        ref = fast_ops.sample_from_triplane(co[img:img + 1, idx].cpu(), planes[img:img + 1].cpu().contiguous())
+        got = flat.reshape(n, -1, C)[img, idx]
+        assert_close(got, ref, rtol=1e-5, atol=2e-5, what=f'image {img}')
