@@ -106,6 +106,20 @@ def _demod_coefs(weight, styles):
 _wsq_cache = {}
 _noise_cache = {}
 _wscale_cache = {}
+_cat_cache = {}
+
+
+def _cat_cached(a, b):
+    """torch.cat([a, b]) of two parameters, formed once per (tensor objects, versions) in inference."""
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return torch.cat([a, b])
+    ent = _cat_cache.get(id(a))
+    if ent is None or ent[0]() is not a or ent[1]() is not b or ent[2] != (a._version, b._version):
+        if len(_cat_cache) > 512:
+            _cat_cache.clear()
+        ent = (weakref.ref(a), weakref.ref(b), (a._version, b._version), torch.cat([a.detach(), b.detach()]))
+        _cat_cache[id(a)] = ent
+    return ent[3]
 
 
 def _scaled_weight(weight, gain):
@@ -245,7 +259,7 @@ def _dual_head(x, torgb, toseg, w):
         wr = torgb.weight[None, :, :, 0, 0] * s_rgb[:, None, :]           # [N, Co_rgb, Cin]
         ws = toseg.weight[None, :, :, 0, 0] * s_seg[:, None, :]
         wcat = torch.cat([wr, ws], dim=1)[:, :, :, None, None].contiguous()
-    bias = torch.cat([torgb.bias, toseg.bias]).to(x.dtype)
+    bias = _cat_cached(torgb.bias, toseg.bias)
     clamp = -1.0 if torgb.conv_clamp is None else torgb.conv_clamp
     y = _modconv_plugin.modconv2d(x.contiguous(), wcat, None, None, None, 0.0, bias, 1, 0.0, 1.0, clamp)
     co = torgb.weight.shape[0]
@@ -275,7 +289,12 @@ class FullyConnectedLayer(torch.nn.Module):
         return w, b
 
     def forward(self, x):
-        w, b = self.effective(x.dtype)
+        if _inference_on_gpu(x, self.weight, self.bias):
+            # gains folded into the parameters once per (tensor, version): two element-wise launches less per layer
+            w = _scaled_weight(self.weight, self.weight_gain)
+            b = None if self.bias is None else (_scaled_weight(self.bias, self.bias_gain) if self.bias_gain != 1 else self.bias)
+        else:
+            w, b = self.effective(x.dtype)
         if self.activation == 'linear' and b is not None:
             return torch.addmm(b.unsqueeze(0), x, w.t())
         x = x.matmul(w.t())

@@ -278,6 +278,22 @@ class LookAtPoseSampler:
 
 # ---- fused renderer (new entry point) -------------------------------------------------------------------
 
+_ray_setup_cache = {}
+
+
+def _fused_ray_setup(device, fov, resolution, num_steps, ray_start, ray_end):
+    """Camera-space ray directions [W*H, 3] and the depth ramp [S] of the fused kernel: they depend on the camera model
+    only, so they are built once per configuration instead of by ~15 tiny launches per frame (read-only afterwards)."""
+    key = (str(device), fov, resolution, num_steps, ray_start, ray_end)
+    ent = _ray_setup_cache.get(key)
+    if ent is None:
+        if len(_ray_setup_cache) > 64:
+            _ray_setup_cache.clear()
+        ent = (_camera_rays(device, fov, resolution).contiguous(), torch.linspace(ray_start, ray_end, num_steps, device=device))
+        _ray_setup_cache[key] = ent
+    return ent
+
+
 def render_triplane_fused(tex_planes, geo_planes, mlp, cam2world, fov, resolution, num_steps, ray_start, ray_end,
                           jitter=None, sigma_noise=None, clamp_mode='softplus', white_back=False, max_depth=None):
     """One HIP launch for: get_initial_rays_trig -> perturb_points -> cam2world transform -> two
@@ -295,8 +311,7 @@ def render_triplane_fused(tex_planes, geo_planes, mlp, cam2world, fov, resolutio
     _init()
     device = tex_planes.device
     W, H = resolution
-    rays_d_cam = _camera_rays(device, fov, resolution)
-    z_lin = torch.linspace(ray_start, ray_end, num_steps, device=device)
+    rays_d_cam, z_lin = _fused_ray_setup(device, float(fov), tuple(resolution), int(num_steps), float(ray_start), float(ray_end))
     if tex_planes.stride(1) != 1:
         tex_planes = tex_planes.contiguous(memory_format=torch.channels_last)
     if geo_planes.stride(1) != 1:
