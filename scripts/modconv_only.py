@@ -35,3 +35,18 @@ for (n, cin, cout, res) in ((4, 512, 256, 64), (4, 256, 128, 128), (4, 128, 64, 
     ms = e0.elapsed_time(e1) / iters
     fl = 2 * cin * cout * 9 * res * res * n
     print(f'tconv n={n} {cin}->{cout} in@{res}: {ms*1e3:.1f} us, {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)')
+print('--- dual heads: per-image 1x1 weights, 96 + 96 (voxel blocks) and 3 + 19 (SR blocks) output channels ---')
+for (n, cin, cout, res) in ((4, 128, 192, 256), (4, 256, 192, 128), (4, 512, 192, 64), (4, 64, 22, 512), (4, 128, 22, 256)):
+    x = torch.randn(n, cin, res, res, generator=g).to(dev); w = torch.randn(n, cout, cin, 1, 1, generator=g).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    f = lambda: hip_plugin.ModconvPlugin.modconv2d(x, w, None, None, None, 0.0, b, 1, 0.0, 1.0, 256.0)
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2 * cin * cout * res * res * n
+    by = (cin + cout) * res * res * n * 4
+    print(f'heads n={n} {cin}->{cout} @{res}: {ms*1e3:.1f} us, {fl/ms/1e9:.1f} TFLOP/s, {by/ms/1e6:.0f} GB/s of x + y')
