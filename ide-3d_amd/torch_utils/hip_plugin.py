@@ -176,6 +176,7 @@ def load():
                                                vp, ctypes.POINTER(i64 * 4), vp, vp],
             'ide3d_composite': [vp, vp, vp, vp, i64, i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32,
                                 ctypes.c_int, vp, vp, vp, vp],
+            'ide3d_sample_pdf': [vp, vp, vp, i64, i64, i32, i32, f32, vp, vp],
             'ide3d_render_rays': [ctypes.POINTER(_RenderParams), vp],
             'ide3d_sample_voxel': [ctypes.POINTER(_RenderParams), vp, i64, vp, vp, ctypes.c_int, vp],
             'ide3d_lattice_points': [ctypes.POINTER(_Lattice), i64, i64, vp, vp],
@@ -197,7 +198,7 @@ def load():
 EXPORTED_SYMBOLS = (
     'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
-    'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_render_rays', 'ide3d_sample_voxel',
+    'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
 )
@@ -532,6 +533,24 @@ class VolumeRenderPlugin:
                                         int(fill_mode), _ptr(rgb), _ptr(depth), _ptr(weights), _stream(rgb_sigma))
         _check(rc, 'composite')
         return rgb, depth, weights
+
+    @staticmethod
+    def sample_pdf(bins, weights, u, eps=1e-5):
+        """bins [rays, k+1], weights [rays, k], u [n_importance] (shared) or [rays, n_importance] -> [rays, n_importance]."""
+        _require(weights.is_cuda and weights.dtype == torch.float32 and weights.ndim == 2, 'weights must be 2-D float32 on a CUDA device')
+        rays, k = weights.shape
+        _require(bins.shape == (rays, k + 1) and bins.dtype == torch.float32 and bins.device == weights.device,
+                 'bins must be [rays, k + 1] float32 next to weights')
+        _require(u.dtype == torch.float32 and u.device == weights.device and u.ndim in (1, 2) and (u.ndim == 1 or u.shape[0] == rays),
+                 'u must be [n_importance] or [rays, n_importance] float32 next to weights')
+        bins, weights, u = bins.contiguous(), weights.contiguous(), u.contiguous()
+        n_imp = u.shape[-1]
+        out = torch.empty([rays, n_imp], dtype=torch.float32, device=weights.device)
+        with torch.cuda.device(weights.device):
+            rc = load().ide3d_sample_pdf(_ptr(bins), _ptr(weights), _ptr(u), 0 if u.ndim == 1 else n_imp, rays, k, n_imp,
+                                         float(eps), _ptr(out), _stream(weights))
+        _check(rc, 'sample_pdf')
+        return out
 
     @staticmethod
     def _fill_render_params(p, tex_planes, geo_planes, mlp):

@@ -63,6 +63,7 @@ class GeneratorSpec:
     fov: float = 18.0
     conv_clamp: Optional[float] = None
     clamp_mode: str = 'softplus'
+    hierarchical: bool = False        # second, importance-sampled pass of `num_steps` more samples per ray
 
     def sr_resolutions(self) -> List[int]:
         # two 2x blocks end at img_resolution: e.g. 64 -> (bilinear 128) -> 256 -> 512
@@ -175,11 +176,15 @@ class TriplaneRenderer(torch.nn.Module):
 
     # -- full rendering -----------------------------------------------------------------------------------
     def forward(self, img_v, seg_v, cam2world, fov=None, num_steps=None, ray_start=None, ray_end=None, img_size=None,
-                nerf_noise=0.0, jitter=None, sigma_noise=None, white_back=False, clamp_mode=None, **unused):
+                nerf_noise=0.0, jitter=None, sigma_noise=None, white_back=False, clamp_mode=None,
+                hierarchical=None, importance_u=None, sigma_noise_fine=None, **unused):
         """Render N views.  Returns (features [N, feat+seg, R, R], depth [N, 1, R, R], weight sum [N, 1, R, R]).
 
         jitter: None -> draw U[0,1) per sample on the device (the reference always jitters,
                 volumetric_rendering.py:113); False -> no jitter; tensor [N, R*R, S] -> use these draws.
+        hierarchical: add the importance pass — S more depths per ray drawn with `sample_pdf` from the first pass's
+                weights, queried, merged by depth and integrated together (2S samples).  `importance_u` [N*R*R, S] supplies
+                the draws (None -> torch.rand); `sigma_noise_fine` [N, R*R, 2S] the density noise of the merged integration.
         """
         sp = self.spec
         fov = sp.fov if fov is None else fov
@@ -197,7 +202,8 @@ class TriplaneRenderer(torch.nn.Module):
         if sigma_noise is None and nerf_noise:
             sigma_noise = torch.randn([n, rays, steps], device=device) * nerf_noise
 
-        if self._hip_ok(img_v, seg_v, cam2world):
+        hierarchical = sp.hierarchical if hierarchical is None else hierarchical
+        if not hierarchical and self._hip_ok(img_v, seg_v, cam2world):
             res = vr.render_triplane_fused(_as_channels_last(img_v), _as_channels_last(seg_v), self.decoder.kernel_weights(),
                                            cam2world.float(), fov, (size, size), steps, t0, t1, jitter=jitter,
                                            sigma_noise=sigma_noise, clamp_mode=clamp_mode, white_back=white_back)
@@ -206,13 +212,27 @@ class TriplaneRenderer(torch.nn.Module):
 
         # step-wise definition (CPU / autograd / configurations outside the fused kernel)
         points, z_vals, rays_d_cam = vr.get_initial_rays_trig(n, steps, device, fov, (size, size), t0, t1)
-        pts, z_vals, _rd, _ro, _p, _y = vr.transform_sampled_points(
+        pts, z_vals, rays_d, rays_o, _p, _y = vr.transform_sampled_points(
             points, z_vals, rays_d_cam, device, h_stddev=0, v_stddev=0, camera=cam2world, mode=None,
             jitter=(jitter.unsqueeze(-1) if jitter is not None else torch.full_like(z_vals, 0.5)))
         out = self.sample_voxel(img_v, seg_v, pts.reshape(n, -1, 3), ray_grid=(size, size, steps)).reshape(n, rays, steps, -1)
         noise = sigma_noise.unsqueeze(-1) if sigma_noise is not None else None
-        feat, depth, weights = vr.fancy_integration(out, rays_d_cam, z_vals, device, noise_std=(1.0 if noise is not None else 0.0),
-                                                    white_back=white_back, clamp_mode=clamp_mode, noise=noise)
+        integrate = lambda o, z, nz: vr.fancy_integration(o, rays_d_cam, z, device, noise_std=(1.0 if nz is not None else 0.0),
+                                                          white_back=white_back, clamp_mode=clamp_mode, noise=nz)
+        if hierarchical:
+            with torch.no_grad():
+                _f, _d, w = integrate(out, z_vals, noise)
+                w = w.reshape(n * rays, steps) + 1e-5
+                z = z_vals.reshape(n * rays, steps)
+                z_fine = vr.sample_pdf(0.5 * (z[:, :-1] + z[:, 1:]), w[:, 1:-1], steps, det=False, u=importance_u)
+                z_fine = z_fine.reshape(n, rays, steps, 1)
+                pts_fine = rays_o.unsqueeze(2) + rays_d.unsqueeze(2) * z_fine
+            out_fine = self.sample_voxel(img_v, seg_v, pts_fine.reshape(n, -1, 3)).reshape(n, rays, steps, -1)
+            z_vals = torch.cat([z_fine, z_vals], 2)
+            z_vals, order = torch.sort(z_vals, dim=2)
+            out = torch.gather(torch.cat([out_fine, out], 2), 2, order.expand(-1, -1, -1, out.shape[-1]))
+            noise = sigma_noise_fine.unsqueeze(-1) if sigma_noise_fine is not None else None
+        feat, depth, weights = integrate(out, z_vals, noise)
         feat = feat.permute(0, 2, 1).reshape(n, -1, size, size)
         depth = depth.permute(0, 2, 1).reshape(n, 1, size, size)
         wsum = weights.sum(2).permute(0, 2, 1).reshape(n, 1, size, size)
@@ -315,7 +335,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         feat, depth, wsum = self.renderer(
             img_v, seg_v, cam2world, fov=render_params.get('fov'), num_steps=render_params.get('num_steps'),
             ray_start=render_params.get('ray_start'), ray_end=render_params.get('ray_end'),
-            nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter)
+            nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter,
+            hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
         img, seg = self.superres(feat, block_ws, **block_kwargs)
         img_raw = feat[:, :self.img_channels]
         if return_dict:

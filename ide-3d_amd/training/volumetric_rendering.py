@@ -28,7 +28,7 @@ _plugin = None
 def _init():
     global _plugin
     if _plugin is None:
-        _plugin = custom_ops.get_plugin(module_name='volume_render_plugin', sources=['composite.hip', 'raymarch.hip'])
+        _plugin = custom_ops.get_plugin(module_name='volume_render_plugin', sources=['composite.hip', 'raymarch.hip', 'sample_pdf.hip'])
     return True
 
 
@@ -234,18 +234,21 @@ def create_world2cam_matrix(forward_vector, origin, device=None):
     return torch.inverse(create_cam2world_matrix(forward_vector, origin, device=device))
 
 
-def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
     """Inverse-CDF sampling of `N_importance` depths per ray (reference :224-265).
-    bins [rays, K+1], weights [rays, K] -> samples [rays, N_importance]."""
+    bins [rays, K+1], weights [rays, K] -> samples [rays, N_importance].  `u` (not in the reference) supplies the
+    draws, [N_importance] or [rays, N_importance], instead of the linspace (`det`) / `torch.rand` the call makes.
+    float32 device tensors run `ide3d_sample_pdf` (one wave per ray); everything else the definition below."""
     n_rays, k = weights.shape
+    if u is None:
+        u = torch.linspace(0, 1, N_importance, device=bins.device) if det else torch.rand(n_rays, N_importance, device=bins.device)
+    if weights.device.type == 'cuda' and weights.dtype == torch.float32 and _init() \
+            and not (torch.is_grad_enabled() and (weights.requires_grad or bins.requires_grad)):
+        return _plugin.sample_pdf(bins.float(), weights, u.float(), eps)
+    u = u.expand(n_rays, N_importance).contiguous()
     pdf = (weights + eps)
     pdf = pdf / pdf.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
-    if det:
-        u = torch.linspace(0, 1, N_importance, device=bins.device).expand(n_rays, N_importance)
-    else:
-        u = torch.rand(n_rays, N_importance, device=bins.device)
-    u = u.contiguous()
     idx = torch.searchsorted(cdf, u)
     lo = torch.clamp_min(idx - 1, 0)
     hi = torch.clamp_max(idx, k)

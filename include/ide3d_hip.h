@@ -225,6 +225,19 @@ int ide3d_composite(const float* rgb_sigma, const float* z_vals, const float* di
                     int clamp_mode, int last_back, int white_back, float max_depth,
                     int fill_mode, float* rgb, float* depth, float* weights, void* stream);
 
+/* ---- importance resampling ------------------------------------------------------------- */
+/*
+ * Replaces `training.volumetric_rendering.sample_pdf` (volumetric_rendering.py:224-265), the
+ * inverse-CDF draw of the optional hierarchical pass.  bins: float32 [rays, k+1], weights:
+ * [rays, k] (both contiguous), u: the draws in [0, 1] — row `r` starts at u + r * u_ray_stride
+ * (0 = one row shared by all rays, the `det=True` linspace), samples: [rays, n_importance].
+ * Row sums / prefix sums are accumulated in double and rounded per element like ATen's CPU
+ * kernels; everything after the cdf is the reference's float expression without contraction.
+ */
+int ide3d_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_ray_stride,
+                     int64_t rays, int32_t k, int32_t n_importance, float eps, float* samples,
+                     void* stream);
+
 /* ---- fused ray-marcher ------------------------------------------------------------------ */
 /*
  * One launch for steps 3-7 of G.synthesis: camera-space sample points

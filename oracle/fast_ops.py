@@ -23,6 +23,7 @@ camera_position = _precise.camera_position
 lookat_pose = _precise.lookat_pose
 create_samples = _precise.create_samples
 frame_u8 = _precise.frame_u8
+sample_pdf = _precise.sample_pdf
 
 _ACTS = {
     'linear': lambda x, a: x,

@@ -149,17 +149,37 @@ def sample_voxel(sd, spec, img_v, seg_v, pts, ops=precise_ops):
     return torch.cat([t, g[:, 1:], g[:, :1]], dim=1)
 
 
-def render(sd, spec, img_v, seg_v, cam2world, jitter=None, sigma_noise=None, ops=precise_ops, num_steps=None):
-    """-> features [N, feat+seg, R, R], depth [N, 1, R, R], weight sum [N, 1, R, R]."""
+def render(sd, spec, img_v, seg_v, cam2world, jitter=None, sigma_noise=None, ops=precise_ops, num_steps=None,
+           hierarchical=False, importance_u=None):
+    """-> features [N, feat+seg, R, R], depth [N, 1, R, R], weight sum [N, 1, R, R].
+    hierarchical: SURVEY.md 3.5 step 6 — the first pass's weights (+1e-5, end samples dropped) define a pdf over the
+    depth mid-points, `sample_pdf` draws `steps` more depths per ray with `importance_u` [N*R*R, steps], those points
+    are queried, both sets are merged by depth and integrated together."""
     n = img_v.shape[0]
     size = spec.render_size
     steps = spec.num_steps if num_steps is None else num_steps
     points, z_vals, d_cam = ops.initial_rays(n, steps, spec.fov, (size, size), spec.ray_start, spec.ray_end)
     if jitter is not None:
         points, z_vals = ops.perturb(points, z_vals, d_cam, jitter.reshape(n, size * size, steps, 1))
-    world = ops.to_world(points, cam2world.float())
+    cam2world = cam2world.float()
+    world = ops.to_world(points, cam2world)
     out = sample_voxel(sd, spec, img_v, seg_v, world.reshape(n, -1, 3), ops).reshape(n, size * size, steps, -1)
     noise = None if sigma_noise is None else sigma_noise.reshape(n, size * size, steps, 1)
+    if hierarchical:
+        rays = size * size
+        _, _, w = ops.composite(out, d_cam, z_vals, noise=noise, clamp_mode=spec.clamp_mode)
+        w = w.reshape(n * rays, steps) + 1e-5
+        z = z_vals.reshape(n * rays, steps)
+        z_fine = ops.sample_pdf(0.5 * (z[:, :-1] + z[:, 1:]), w[:, 1:-1], importance_u).reshape(n, rays, steps, 1)
+        rot_only = cam2world.clone()
+        rot_only[:, :3, 3] = 0
+        dirs = ops.to_world(d_cam, rot_only)                                   # [n, rays, 3]
+        origin = cam2world[:, None, None, :3, 3]
+        fine = origin + dirs[:, :, None, :] * z_fine
+        out_f = sample_voxel(sd, spec, img_v, seg_v, fine.reshape(n, -1, 3), ops).reshape(n, rays, steps, -1)
+        z_vals, order = torch.sort(torch.cat([z_fine, z_vals], 2), dim=2)
+        out = torch.gather(torch.cat([out_f, out], 2), 2, order.expand(-1, -1, -1, out.shape[-1]))
+        noise = None
     feat, depth, weights = ops.composite(out, d_cam, z_vals, noise=noise, clamp_mode=spec.clamp_mode)
     feat = feat.permute(0, 2, 1).reshape(n, -1, size, size)
     depth = depth.permute(0, 2, 1).reshape(n, 1, size, size)

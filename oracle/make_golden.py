@@ -193,6 +193,17 @@ def gen_volumetric():
     zmid = 0.5 * (zz[:, :, :-1, 0] + zz[:, :, 1:, 0]).reshape(18, 12)
     wts = torch.rand(18, 11, generator=g)
     cases.append(dict(cfg=dict(fn='sample_pdf', N_importance=9), in_bins=zmid, in_w=wts, out_samples=r_vr.sample_pdf(zmid, wts, 9, det=True)))
+    # ... with random draws (det=False): the reference's first RNG call after seeding is `torch.rand(rays, N_importance)`,
+    # so the draws can be stored next to the result.  Includes empty bins (denom < eps) and an all-zero ray.
+    g2 = torch.Generator().manual_seed(33)
+    bins2 = torch.sort(torch.rand(40, 23, generator=g2) * 1.05 + 2.25, dim=1)[0]
+    w2 = torch.rand(40, 22, generator=g2)
+    w2[:, 5:9] = 0
+    w2[3] = 0
+    w2[7, :20] = 0
+    torch.manual_seed(77); u2 = torch.rand(40, 24)
+    torch.manual_seed(77); s2 = r_vr.sample_pdf(bins2, w2, 24, det=False)
+    cases.append(dict(cfg=dict(fn='sample_pdf_rand', N_importance=24), in_bins=bins2, in_w=w2, in_u=u2, out_samples=s2))
     save('volumetric', cases)
 
 

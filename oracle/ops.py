@@ -378,6 +378,23 @@ def sample_pdf_det(bins, weights, n_importance, eps=1e-5):
     return out
 
 
+def sample_pdf(bins, weights, u, eps=1e-5):
+    """sample_pdf (volumetric_rendering.py:224-265) with the draws `u` [rays, n] given (the reference makes them with
+    `torch.linspace` / `torch.rand`); vectorised, float32 like the reference."""
+    w = weights.float() + eps
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    K = weights.shape[1]
+    u = u.float().expand(weights.shape[0], -1).contiguous()
+    idx = torch.searchsorted(cdf, u)
+    lo, hi = (idx - 1).clamp(min=0), idx.clamp(max=K)
+    c0, c1 = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b0, b1 = torch.gather(bins.float(), 1, lo), torch.gather(bins.float(), 1, hi)
+    den = c1 - c0
+    den = torch.where(den < eps, torch.ones_like(den), den)
+    return b0 + (u - c0) / den * (b1 - b0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # post-processing  (dnnlib/seg_tools.py:13-32,75-81; dnnlib/util.py:632-646; extract_shapes.py:74-96)
 # ---------------------------------------------------------------------------------------------------

@@ -348,6 +348,67 @@ def test_fancy_integration_96_steps_52_channels(gpu_device):
 
 # ---- modulated convolution (fp32 MFMA implicit GEMM) ---------------------------------------------------------------------
 
+def test_sample_pdf_kernel(golden, gpu_device):
+    """`ide3d_sample_pdf` against the reference-run vectors (det linspace; random draws with empty bins and an all-zero
+    ray), against the oracle at the benchmark shape, and on degenerate shapes.  Tolerance 2e-6 relative to the depth
+    range: the cdf is rounded from double prefix sums like ATen's CPU cumsum, the rest is the same float expression."""
+    from training import volumetric_rendering as vr
+    from torch_utils import hip_plugin
+    hip_plugin.CALLS.clear()
+    (cfg, a), = golden('volumetric').select(fn='sample_pdf')
+    s = vr.sample_pdf(t(a['in_bins'], gpu_device), t(a['in_w'], gpu_device), cfg['N_importance'], det=True)
+    assert_close(s, a['out_samples'], rtol=2e-6, atol=2e-6, what='sample_pdf det')
+    (cfg, a), = golden('volumetric').select(fn='sample_pdf_rand')
+    s = vr.sample_pdf(t(a['in_bins'], gpu_device), t(a['in_w'], gpu_device), cfg['N_importance'], u=t(a['in_u'], gpu_device))
+    assert_close(s, a['out_samples'], rtol=2e-6, atol=2e-6, what='sample_pdf rand')
+    assert _calls('sample_pdf') == 2
+    # benchmark shape: 4 x 4096 rays, 96 coarse samples -> 95 mid-points, 94 weights, 96 draws; peaked weights like a surface
+    g = torch.Generator().manual_seed(12)
+    rays, steps = 4 * 4096, 96
+    z = torch.sort(torch.rand(rays, steps, generator=g) * 1.05 + 2.25, dim=1)[0]
+    w = torch.exp(-((torch.arange(steps)[None] - torch.randint(5, 90, (rays, 1), generator=g)) / 3.0) ** 2) * torch.rand(rays, steps, generator=g)
+    w[::7, :40] = 0
+    bins, wts = 0.5 * (z[:, :-1] + z[:, 1:]), (w + 1e-5)[:, 1:-1]
+    u = torch.rand(rays, steps, generator=g)
+    got = vr.sample_pdf(bins.to(gpu_device), wts.to(gpu_device), steps, u=u.to(gpu_device))
+    want = oracle_ops.sample_pdf(bins, wts, u)
+    # `denom < eps -> 1` and the bin search make the reference function discontinuous: where a bin's mass is within an ulp
+    # of eps, two correct float evaluations can land on different branches.  Element-wise agreement is therefore required
+    # for all but a 1e-4 fraction, and every sample must satisfy the defining property  cdf(sample) = u  (checked against
+    # a float64 piece-wise linear cdf; on either branch the deviation is bounded by the mass eps of the bin).
+    err = (got.cpu() - want).abs()
+    assert float((err > 5e-6).float().mean()) < 1e-4, f'sample_pdf at the benchmark shape: {int((err > 5e-6).sum())} elements differ'
+    def cdf_at(smp):
+        pd = (wts.double() + 1e-5)
+        cd = torch.cat([torch.zeros(rays, 1, dtype=torch.float64), torch.cumsum(pd / pd.sum(-1, keepdim=True), -1)], -1)
+        bd = bins.double()
+        i = (torch.searchsorted(bd, smp.double().contiguous(), right=True) - 1).clamp(0, bd.shape[1] - 2)
+        b0, b1 = torch.gather(bd, 1, i), torch.gather(bd, 1, i + 1)
+        c0, c1 = torch.gather(cd, 1, i), torch.gather(cd, 1, i + 1)
+        # tolerance: the mass eps of a bin on the `denom -> 1` branch + a float32 ulp of the depth (2.4e-7 near 3) times the
+        # steepest cdf slope of the ray
+        steepest = ((cd[:, 1:] - cd[:, :-1]) / (bd[:, 1:] - bd[:, :-1])).max(-1, keepdim=True)[0]
+        return c0 + (smp.double() - b0) / (b1 - b0) * (c1 - c0), 2e-5 + steepest * 5e-7
+    f_got, f_tol = cdf_at(got.cpu())
+    assert bool(((f_got - u.double()).abs() <= f_tol).all()), 'cdf(sample) != u'
+    assert bool((got.cpu() >= bins[:, :1] - 1e-6).all() and (got.cpu() <= bins[:, -1:] + 1e-6).all()), 'samples stay inside the bins'
+    # size-independent property: sorted draws give sorted samples (the inverse cdf is monotone)
+    us = torch.sort(u, dim=1)[0]
+    srt = vr.sample_pdf(bins.to(gpu_device), wts.to(gpu_device), steps, u=us.to(gpu_device)).cpu()
+    assert bool((srt[:, 1:] >= srt[:, :-1] - 1e-6).all())
+    # degenerate shapes: one bin, one draw, shared draws, more weights than one wave pass, no rays
+    for k, n_imp, r in ((1, 1, 3), (1, 5, 2), (200, 7, 5), (2048, 64, 2)):
+        b = torch.sort(torch.rand(r, k + 1, generator=g), dim=1)[0]
+        ww = torch.rand(r, k, generator=g)
+        uu = torch.rand(n_imp, generator=g)
+        got = vr.sample_pdf(b.to(gpu_device), ww.to(gpu_device), n_imp, u=uu.to(gpu_device))
+        assert_close(got, oracle_ops.sample_pdf(b, ww, uu[None]), rtol=0, atol=2e-6, what=f'sample_pdf k={k} n={n_imp}')
+    assert vr.sample_pdf(torch.zeros(0, 5, device=gpu_device), torch.zeros(0, 4, device=gpu_device), 3, det=True).shape == (0, 3)
+    with pytest.raises(RuntimeError):
+        hip_plugin.VolumeRenderPlugin.sample_pdf(torch.zeros(2, 4000, device=gpu_device), torch.zeros(2, 3999, device=gpu_device),
+                                                 torch.zeros(4, device=gpu_device))
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,k', [(2, 8, 16, 4, 4, 3), (1, 20, 150, 19, 33, 3), (3, 32, 96, 16, 16, 1), (2, 64, 3, 40, 24, 1),
                                             (1, 128, 128, 32, 32, 3), (2, 6, 19, 9, 70, 1)])
 def test_modconv2d_against_conv2d(gpu_device, n, cin, cout, h, w, k):

@@ -120,6 +120,48 @@ def test_fused_renderer_full_size_vs_stepwise_and_oracle(gpu_device):
     _rel(depth[0].reshape(4096)[rays], do[0, :, 0], 1e-4, 'fused vs oracle depth')
 
 
+def test_hierarchical_pass_gpu(golden, gpu_device):
+    """Importance pass on the HIP ops (sample_voxel, composite, sample_pdf kernels + torch sort) vs the CPU oracle: tiny
+    configuration from the reference-built fixture, and one full-size image (64 x 64 rays, 96 + 96 samples)."""
+    from torch_utils import hip_plugin
+    from training import triplane
+    G, cfg, a = _load(golden, gpu_device)
+    sp = G.synthesis.renderer.spec
+    rays, steps = sp.render_size ** 2, sp.num_steps
+    u = torch.rand(2 * rays, steps, generator=torch.Generator().manual_seed(5))
+    cam = t(a['in_c'])[:, :16].reshape(-1, 4, 4)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    want = ogen.render(sd, ospec.tiny(), t(a['out_img_v']), t(a['out_seg_v']), cam, jitter=t(a['in_jitter']), hierarchical=True, importance_u=u)
+    hip_plugin.CALLS.clear()
+    with torch.no_grad():
+        got = G.synthesis.renderer(t(a['out_img_v'], gpu_device), t(a['out_seg_v'], gpu_device), cam.to(gpu_device),
+                                   jitter=t(a['in_jitter'], gpu_device), hierarchical=True, importance_u=u.to(gpu_device))
+    assert _calls('sample_pdf') == 1 and _calls('sample_voxel') == 2 and _calls('composite') == 2 and _calls('render_rays') == 0
+    _rel(got[0], want[0], 3e-4, 'hierarchical features (tiny)')
+    _rel(got[1], want[1], 1e-4, 'hierarchical depth (tiny)')
+    # full size, one image
+    torch.manual_seed(0)
+    fsp = triplane.GeneratorSpec()
+    R = triplane.TriplaneRenderer(fsp).eval()
+    with torch.no_grad():
+        for p in R.parameters():
+            if p.ndim == 1:
+                p.copy_(torch.randn_like(p) * 0.2)
+    g = torch.Generator().manual_seed(3)
+    tex, geo = torch.randn(1, 96, 256, 256, generator=g) * 0.7, torch.randn(1, 96, 256, 256, generator=g) * 0.7
+    cam = triplane.camera_label(0.3)[:, :16].reshape(-1, 4, 4)
+    jit, u = torch.rand(1, 4096, 96, generator=g), torch.rand(4096, 96, generator=g)
+    sd = {'synthesis.renderer.' + k: v.detach() for k, v in R.state_dict().items()}
+    want = ogen.render(sd, ospec.Spec(), tex, geo, cam, jitter=jit, ops=fast_ops, hierarchical=True, importance_u=u)
+    R = R.to(gpu_device)
+    with torch.no_grad():
+        got = R(tex.to(gpu_device), geo.to(gpu_device), cam.to(gpu_device), jitter=jit.to(gpu_device), hierarchical=True,
+                importance_u=u.to(gpu_device))
+    _rel(got[0], want[0], 5e-4, 'hierarchical features (full size)')
+    _rel(got[1], want[1], 2e-4, 'hierarchical depth (full size)')
+    _rel(got[2], want[2], 2e-4, 'hierarchical weight sum (full size)')
+
+
 def test_generator_full_size_vs_oracle(gpu_device):
     """Random-init ide3d-ffhq-64-512 generator, one image: HIP path vs the CPU oracle (fp32 torch formulation)."""
     from training import triplane

@@ -150,6 +150,12 @@ def test_volumetric_cpu(golden):
         elif fn == 'sample_pdf':
             s = vr.sample_pdf(t(a['in_bins']), t(a['in_w']), cfg['N_importance'], det=True)
             assert_close(s, a['out_samples'], rtol=1e-6, atol=1e-6, what='sample_pdf')
+        elif fn == 'sample_pdf_rand':
+            s = vr.sample_pdf(t(a['in_bins']), t(a['in_w']), cfg['N_importance'], u=t(a['in_u']))
+            assert_close(s, a['out_samples'], rtol=1e-6, atol=1e-6, what='sample_pdf rand')
+            torch.manual_seed(77)         # the call draws `torch.rand(rays, N)` first, like the reference
+            s = vr.sample_pdf(t(a['in_bins']), t(a['in_w']), cfg['N_importance'], det=False)
+            assert_close(s, a['out_samples'], rtol=1e-6, atol=1e-6, what='sample_pdf det=False')
     with pytest.raises(ValueError):
         vr.fancy_integration(torch.zeros(1, 1, 2, 4), torch.ones(1, 1, 3), torch.zeros(1, 1, 2, 1), 'cpu', noise_std=0, clamp_mode=None)
 
@@ -209,6 +215,28 @@ def test_generator_matches_reference_assembly_cpu(golden):
     assert_close(sv, a['out_sample_out'], rtol=1e-4, atol=1e-5, what='sample_voxel')
     img, seg = G.synthesis(t(a['out_ws']), c=t(a['in_c']), ray_jitter=t(a['in_jitter']), return_seg=True)
     assert img.shape == (2, 3, 64, 64) and seg.shape == (2, 5, 64, 64)
+
+
+def test_hierarchical_pass_cpu(golden):
+    """Importance pass of the renderer (CPU step-wise path) == the oracle's composition of the same reference functions."""
+    from oracle import generator as ogen, spec as ospec
+    G, cfg, a = load_golden_generator(golden)
+    sp = G.synthesis.renderer.spec
+    n, rays, steps = 2, sp.render_size ** 2, sp.num_steps
+    u = torch.rand(n * rays, steps, generator=torch.Generator().manual_seed(5))
+    cam = t(a['in_c'])[:, :16].reshape(-1, 4, 4)
+    sd = {k: v.detach() for k, v in G.state_dict().items()}
+    want = ogen.render(sd, ospec.tiny(), t(a['out_img_v']), t(a['out_seg_v']), cam, jitter=t(a['in_jitter']), hierarchical=True,
+                       importance_u=u)
+    with torch.no_grad():
+        got = G.synthesis.renderer(t(a['out_img_v']), t(a['out_seg_v']), cam, jitter=t(a['in_jitter']), hierarchical=True, importance_u=u)
+        base = G.synthesis.renderer(t(a['out_img_v']), t(a['out_seg_v']), cam, jitter=t(a['in_jitter']))
+    for g_, w_, name in zip(got, want, ('features', 'depth', 'weight sum')):
+        assert_close(g_, w_, rtol=1e-4, atol=1e-5, what=f'hierarchical {name}')
+    assert float((got[0] - base[0]).abs().max()) > 1e-4, 'the importance pass must change the result'
+    out = G.synthesis(t(a['out_ws']), c=t(a['in_c']), ray_jitter=t(a['in_jitter']), render_params=dict(hierarchical=True, importance_u=u),
+                      return_dict=True)
+    assert_close(out['image_depth'], want[1], rtol=1e-4, atol=1e-5, what='hierarchical through G.synthesis')
 
 
 def test_shape_extraction_cpu(golden):
