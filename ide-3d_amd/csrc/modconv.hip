@@ -22,8 +22,11 @@
 //     once per tap with a shifted address (B operand): im2col never materialises;
 //   * transposed convolution: the four output parity classes (oy%2, ox%2) are separate tile sets, each walking
 //     only its own taps (4 / 2 / 2 / 1 of the 9), so no multiplications by inserted zeros are issued;
-//   * global -> register -> LDS double buffering: chunk c+1 is fetched while chunk c feeds the MFMAs, one barrier
-//     per chunk;
+//   * double buffering: chunk c+1 is fetched (weights by LDS-DMA, input patch through registers) while chunk c feeds
+//     the MFMAs, one barrier per chunk.  The MFMA operands are read from LDS by hand-issued `ds_read_b32` with
+//     explicit `s_waitcnt lgkmcnt(n)` (tap t+1 in flight while tap t multiplies): the compiler then sees no LDS load
+//     in the loop and no longer drains `vmcnt` — the weight DMA it cannot disambiguate — before the first operand
+//     read, so the prefetch latency overlaps the MFMAs (+3 % frames/s); phase cycles: scripts/modconv_trace.py;
 //   * split-K (low-resolution 512-channel layers have too few tiles to fill 256 CUs): partial sums go to a
 //     workspace, `modconv_epilogue_kernel` reduces them and applies the epilogue — deterministic, no atomics.
 // Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
@@ -34,6 +37,15 @@
 namespace ide3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef IDE3D_MC_TRACE
+// Developer aid (make EXTRA=-DIDE3D_MC_TRACE): cycles wave 0 of one block spends in each phase of its chunk loop,
+// accumulated in registers and written once after the loop; read back with ide3d_debug_mc().  Not part of the ABI.
+__device__ unsigned long long g_mc_dbg[256];
+#define IDE3D_MC_TS(k) { const unsigned long long now_ = __builtin_readcyclecounter(); mc_acc[k] += now_ - mc_last; mc_last = now_; }
+#else
+#define IDE3D_MC_TS(k)
+#endif
 
 enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3, MODE_CONV3S2 = 4 };
 
@@ -118,28 +130,49 @@ struct ConvGeom {
     int debug;                      // experiments only: 1 = no staging after the first chunk, 2 = staging but no MFMA
 };
 
-template <int MODE, int BIG, int TI, int PH, int PW>
-__global__ void __launch_bounds__(256, (MODE == MODE_TCONV3A) ? 3 : 2)
-modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
-    using K = McCfg<MODE, BIG, TI, PH, PW>;
-    __shared__ __attribute__((aligned(16))) float s_w[2][K::LDS_W];
-    __shared__ __attribute__((aligned(16))) float s_x[2][K::LDS_X];
+// ---- hand-scheduled LDS operand reads ----------------------------------------------------------------------------
+// The MFMA operands are read from LDS with `ds_read_b32` issued from inline assembly and waited for with explicit
+// `s_waitcnt lgkmcnt(n)`: (1) the reads of tap t+1 are in flight while the MFMAs of tap t issue (hipcc otherwise places
+// every read right before its use and waits for it); (2) the compiler sees no LDS load in the loop, so it does not
+// drain `vmcnt` — the LDS-DMA weight copy of the NEXT chunk, which may alias in its view — before the first operand
+// read of THIS chunk: the global latency of a chunk's prefetch now overlaps the MFMAs instead of preceding them.
+template <int OFF_BYTES>
+__device__ __forceinline__ float lds_read_async(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(float& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
+__device__ __forceinline__ void lds_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }
 
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// patch offset (floats) and accumulator set of tap T
+template <int MODE, int XW>
+__host__ __device__ constexpr int tap_patch_offset(int t) {
+    return (MODE == MODE_CONV1) ? 0
+         : (MODE == MODE_TCONV3A) ? ((t / 3 == 2) ? 0 : 1) * XW + ((t % 3 == 2) ? 0 : 1)
+         : (t / 3) * XW + (t % 3);
+}
+template <int MODE>
+__host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3A) ? ((t / 3) & 1) * 2 + ((t % 3) & 1) : 0; }
+
+// One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
+// (MODE_TCONV3 only).  s_w / s_x: two buffers of K::LDS_W / K::LDS_X floats.
+template <int MODE, int BIG, int TI, int PH, int PW>
+__device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, const float* __restrict__ wp, float* __restrict__ partial,
+                                             const ConvGeom& g, float* s_w, float* s_x, int mb, int tl, int grp, int split, int cls,
+                                             int tiles_x) {
+    using K = McCfg<MODE, BIG, TI, PH, PW>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / K::WN, wn = wid % K::WN;
     const int half = lane >> 5, l32 = lane & 31;
-
-    // ---- block decomposition: ((split, img_group, tile), m-block) with m-block fastest (shares the input patch) ----
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mb = bid % g.mblocks; bid /= g.mblocks;
-    const int tiles_per_group = g.tile_base[4];
-    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
-    const int grp = bid % g.img_groups; bid /= g.img_groups;
-    const int split = bid;
-    int cls = 0;
-    if (MODE == MODE_TCONV3) { cls = (tile >= g.tile_base[1]) + (tile >= g.tile_base[2]) + (tile >= g.tile_base[3]); }
-    const int tl = tile - g.tile_base[cls];
-    const int txi = tl % g.tiles_x[cls], tyi = tl / g.tiles_x[cls];
+    const int txi = tl % tiles_x, tyi = tl / tiles_x;
     const int y0 = tyi * PH, x0 = txi * PW;                       // tile origin in (class-)grid coordinates
     const int n0 = grp * TI;
     const int cpy = cls >> 1, cpx = cls & 1;                      // output parity of this class (tconv)
@@ -229,6 +262,9 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     // Weights: global -> LDS by DMA (global_load_lds_dwordx4): the packed slab is already the LDS image, so there is no
     // VGPR round trip and no ds_write; each wave moves every 4th piece.  Input patch: issue-only loads into
     // registers (clamped addresses, no branches); scaling by the styles and zero fill happen in commit().
+#ifdef IDE3D_MC_TRACE
+    unsigned long long mc_acc[6] = {0, 0, 0, 0, 0, 0}, mc_last = 0;
+#endif
     auto fetch = [&](int c, int buf) {
         const float* ws = wsrc + (int64_t)c * (K::WTAPS * K::KC * K::BM);
         for (int i = wid; i < w_pieces; i += 4) {
@@ -236,8 +272,9 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
             const float* src = ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + r + lane * 4;
             if (lane * 4 < PIECE)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(&s_w[buf][t * (K::KC * K::BM) + r]), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(s_w + buf * K::LDS_W + t * (K::KC * K::BM) + r), 16, 0, 0);
         }
+        IDE3D_MC_TS(5)
         const int ci0 = c * K::KC;
 #pragma unroll
         for (int i = 0; i < K::NXE; ++i) {
@@ -254,7 +291,7 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         for (int i = 0; i < K::NXE; ++i) {
             const int cil = x_img[i] % K::KC;
             const bool live = x_src[i] >= 0 && ci0 + cil < p.cin;
-            if (x_dst[i] >= 0) s_x[buf][x_dst[i]] = live ? xreg[i] * sreg[i] : 0.f;
+            if (x_dst[i] >= 0) s_x[buf * K::LDS_X + x_dst[i]] = live ? xreg[i] * sreg[i] : 0.f;
         }
     };
 
@@ -263,11 +300,16 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         commit(0, c_begin);
     }
     __syncthreads();
+#ifdef IDE3D_MC_TRACE
+    mc_last = __builtin_readcyclecounter();
+#endif
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
+        IDE3D_MC_TS(0)
         if (c + 1 < c_end && g.debug != 1) fetch(c + 1, buf ^ 1);
-        const float* sw = s_w[buf];
-        const float* sx = s_x[buf];
+        IDE3D_MC_TS(1)
+        const float* sw = s_w + buf * K::LDS_W;
+        const float* sx = s_x + buf * K::LDS_X;
         auto tap_body = [&](int t, int off, auto cls_tag) {
             constexpr int q = decltype(cls_tag)::value;
 #pragma unroll
@@ -287,21 +329,65 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
         using C0 = std::integral_constant<int, 0>;
         if constexpr (MODE == MODE_TCONV3) {
             for (int t = 0; t < ntaps; ++t) tap_body(t, sel(t_off, t), C0{});
-        } else if constexpr (MODE == MODE_TCONV3A) {
-            // tap (ky, kx) feeds output parity class (ky & 1, kx & 1)
-            tap_body(0, t_off[0], std::integral_constant<int, 0>{}); tap_body(1, t_off[1], std::integral_constant<int, 1>{});
-            tap_body(2, t_off[2], std::integral_constant<int, 0>{}); tap_body(3, t_off[3], std::integral_constant<int, 2>{});
-            tap_body(4, t_off[4], std::integral_constant<int, 3>{}); tap_body(5, t_off[5], std::integral_constant<int, 2>{});
-            tap_body(6, t_off[6], std::integral_constant<int, 0>{}); tap_body(7, t_off[7], std::integral_constant<int, 1>{});
-            tap_body(8, t_off[8], std::integral_constant<int, 0>{});
         } else {
+            // software pipeline over steps = (tap, pair of k-steps): operand set (s & 1) feeds the MFMAs of step s while set
+            // ((s + 1) & 1) is loading
+            constexpr int KP = K::KC / 2, G = 2, SPT = KP / G, NSTEP = K::MAXT * SPT, NRD = G * (K::MTW + K::NTW);
+            static_assert(KP % G == 0 && NRD <= 15, "lgkmcnt is a 4-bit counter");
+            const unsigned a_base = lds_addr(sw + aoff);
+            unsigned b_base[K::NTW];
 #pragma unroll
-            for (int t = 0; t < K::MAXT; ++t) tap_body(t, t_off[t], C0{});
+            for (int j = 0; j < K::NTW; ++j) b_base[j] = lds_addr(sx + boff[j]);
+            float av[2][G][K::MTW], bv[2][G][K::NTW];
+            auto issue = [&](auto ss) {
+                constexpr int S = decltype(ss)::value, T = S / SPT, CP0 = (S % SPT) * G, B = S & 1;
+                static_for<G>([&](auto cc) {
+                    constexpr int CP = CP0 + decltype(cc)::value, CI = decltype(cc)::value;
+                    static_for<K::MTW>([&](auto ii) {
+                        constexpr int I = decltype(ii)::value;
+                        av[B][CI][I] = lds_read_async<((T * K::KC + CP * 2) * K::BM + I * 32) * 4>(a_base);
+                    });
+                    static_for<K::NTW>([&](auto jj) {
+                        constexpr int J = decltype(jj)::value;
+                        bv[B][CI][J] = lds_read_async<(CP * 2 * K::XS + tap_patch_offset<MODE, K::XW>(T)) * 4>(b_base[J]);
+                    });
+                });
+            };
+            issue(C0{});
+            static_for<NSTEP>([&](auto ss) {
+                constexpr int S = decltype(ss)::value, B = S & 1, Q = tap_class<MODE>(S / SPT);
+                if constexpr (S + 1 < NSTEP) issue(std::integral_constant<int, S + 1>{});
+                lds_wait<(S + 1 < NSTEP) ? NRD : 0>(av[B][0][0]);
+#pragma unroll
+                for (int cp = 0; cp < G; ++cp) {
+#pragma unroll
+                    for (int i = 0; i < K::MTW; ++i) lds_pin(av[B][cp][i]);
+#pragma unroll
+                    for (int j = 0; j < K::NTW; ++j) lds_pin(bv[B][cp][j]);
+                }
+#pragma unroll
+                for (int cp = 0; cp < G; ++cp)
+#pragma unroll
+                    for (int i = 0; i < K::MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < K::NTW; ++j)
+                            acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[B][cp][i], bv[B][cp][j], acc[Q][i][j], 0, 0, 0);
+            });
         }
+        IDE3D_MC_TS(2)
         if (c + 1 < c_end && g.debug != 1) commit(buf ^ 1, c + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-DMA weight slab of chunk c + 1 has landed
+        IDE3D_MC_TS(3)
         if (g.debug != 1) __syncthreads();
+        IDE3D_MC_TS(4)
     }
 
+#ifdef IDE3D_MC_TRACE
+    if (blockIdx.x == 100 && threadIdx.x == 0) {
+        for (int k = 0; k < 6; ++k) g_mc_dbg[k] = mc_acc[k];
+        g_mc_dbg[7] = (unsigned long long)(c_end - c_begin);
+    }
+#endif
     // ---- epilogue ----
     const bool raw = (g.split_k > 1);
 #pragma unroll
@@ -338,6 +424,32 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
                 dst[(((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox] = v;
             }
     }
+}
+
+// ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
+struct BlockId { int mb, tile, grp, split; };
+__device__ __forceinline__ BlockId decode_block(const ConvGeom& g) {
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    BlockId b;
+    b.mb = bid % g.mblocks; bid /= g.mblocks;
+    b.tile = bid % g.tile_base[4]; bid /= g.tile_base[4];
+    b.grp = bid % g.img_groups; bid /= g.img_groups;
+    b.split = bid;
+    return b;
+}
+
+template <int MODE, int BIG, int TI, int PH, int PW>
+// 128-pixel (and smaller) tiles: <= 168 VGPRs and <= 53 KB of LDS, three workgroups per CU (measured +2 % frames/s over two);
+// the stride-2 mode's (2P + 1) x (2Q + 1) patches need more LDS than that
+__global__ void __launch_bounds__(256, (TI * PH * PW <= 128 && MODE != MODE_CONV3S2) ? 3 : 2)
+modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
+    using K = McCfg<MODE, BIG, TI, PH, PW>;
+    __shared__ __attribute__((aligned(16))) float s_w[2 * K::LDS_W];
+    __shared__ __attribute__((aligned(16))) float s_x[2 * K::LDS_X];
+    const BlockId b = decode_block(g);
+    int cls = 0;
+    if (MODE == MODE_TCONV3) { cls = (b.tile >= g.tile_base[1]) + (b.tile >= g.tile_base[2]) + (b.tile >= g.tile_base[3]); }
+    modconv_tile<MODE, BIG, TI, PH, PW>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
 }
 
 // reduce split-K partials + epilogue
@@ -496,3 +608,9 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     IDE3D_CHECK_LAUNCH("modconv2d");
     return IDE3D_OK;
 }
+
+#ifdef IDE3D_MC_TRACE
+extern "C" int ide3d_debug_mc(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ide3d::g_mc_dbg), sizeof(unsigned long long) * 256);
+}
+#endif
