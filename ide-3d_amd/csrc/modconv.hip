@@ -83,7 +83,9 @@ struct McCfg {
     static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
     static constexpr int LDS_X = TI * XI;
     static constexpr int NW4 = (LDS_W / 4 + 255) / 256;     // float4 weight loads per thread per chunk
-    static constexpr int NXE = (TI * KC * HP * HW + 255) / 256;   // input elements per thread per chunk
+    // flat 1x1 tiles (one row of PW pixels, no halo) stage the patch in 16-byte pieces
+    static constexpr int VW = (MODE == MODE_CONV1 && PH == 1 && PW % 4 == 0) ? 4 : 1;
+    static constexpr int NXE = (TI * KC * HP * HW / VW + 255) / 256;   // input elements (VW floats each) per thread per chunk
 };
 
 template <int N>
@@ -214,9 +216,9 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     for (int i = 0; i < K::NXE; ++i) {
         const int e = tid + i * 256;
         x_src[i] = -1; x_dst[i] = -1; x_img[i] = 0;
-        if (e < TI * K::KC * K::HP * K::HW) {
+        if (e < TI * K::KC * K::HP * K::HW / K::VW) {
             int r = e;
-            const int rx = r % K::HW; r /= K::HW;
+            const int rx = (r % (K::HW / K::VW)) * K::VW; r /= (K::HW / K::VW);
             const int ry = r % K::HP; r /= K::HP;
             const int cil = r % K::KC; r /= K::KC;
             const int ti = r;
@@ -254,7 +256,10 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
 
     // Staging is split into an issue-only half (unconditional loads from clamped addresses: no exec-mask
     // branches, no vmcnt(0) between loads) and a commit half that runs after the MFMAs of the current chunk.
-    float xreg[K::NXE], sreg[K::NXE];
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    using XV = std::conditional_t<K::VW == 4, f32x4v, float>;
+    XV xreg[K::NXE];
+    float sreg[K::NXE];
     const int img_last = p.n - 1;
     constexpr int PIECE = (K::KC * K::BM < 256) ? K::KC * K::BM : 256;   // floats per LDS-DMA piece (<= 64 lanes x 16 B)
     constexpr int PPT = K::KC * K::BM / PIECE;                            // pieces per tap slab
@@ -281,7 +286,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
             const int cil = x_img[i] % K::KC;
             const int ci = min(ci0 + cil, p.cin - 1);
             const int64_t src = (x_src[i] >= 0) ? (int64_t)x_src[i] + (int64_t)(ci - cil) * hw : 0;
-            xreg[i] = p.x[src];
+            xreg[i] = *reinterpret_cast<const XV*>(p.x + src);
             sreg[i] = p.styles ? p.styles[min(n0 + x_img[i] / K::KC, img_last) * p.cin + ci] : 1.0f;
         }
     };
@@ -291,7 +296,9 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         for (int i = 0; i < K::NXE; ++i) {
             const int cil = x_img[i] % K::KC;
             const bool live = x_src[i] >= 0 && ci0 + cil < p.cin;
-            if (x_dst[i] >= 0) s_x[buf * K::LDS_X + x_dst[i]] = live ? xreg[i] * sreg[i] : 0.f;
+            XV v = xreg[i] * sreg[i];
+            if (!live) __builtin_memset(&v, 0, sizeof(v));
+            if (x_dst[i] >= 0) *reinterpret_cast<XV*>(s_x + buf * K::LDS_X + x_dst[i]) = v;
         }
     };
 
@@ -484,6 +491,15 @@ struct ConvPlan {
     ConvGeom g;
 };
 
+// A 1x1 convolution does not see the image shape: h x w is treated as one row, tiled in runs of 128 pixels whose patch
+// rows are contiguous in memory (16-byte staging, 128-byte output runs).  Needs 16-byte aligned rows.
+static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
+    ide3d_modconv_params p = in;
+    const int64_t hw = (int64_t)p.h * p.w_;
+    if (p.k == 1 && p.mode == 0 && hw % 4 == 0 && hw >= 128 && ((uintptr_t)p.x % 16) == 0 && !getenv("IDE3D_MODCONV_NO_FLAT")) { p.h = 1; p.w_ = (int)hw; }
+    return p;
+}
+
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !getenv("IDE3D_MODCONV_NO_TCONV3A");
@@ -513,7 +529,8 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     }
     if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
     if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
-    static const int TIv[5] = {1, 2, 8, 1, 1}, PHv[5] = {8, 8, 4, 16, 4}, PWv[5] = {16, 8, 4, 16, 16};
+    if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
+    static const int TIv[6] = {1, 2, 8, 1, 1, 1}, PHv[6] = {8, 8, 4, 16, 4, 1}, PWv[6] = {16, 8, 4, 16, 16, 128};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -544,7 +561,11 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
         if constexpr (BIG != 0)
             hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     } else
-    if (pl.tile == 0)      hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    if (pl.tile == 5) {
+        if constexpr (MODE == MODE_CONV1)
+            hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 1, 128>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    }
+    else if (pl.tile == 0) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 8, 4, 4>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if constexpr (BIG == 1 && MODE != MODE_CONV1 && MODE != MODE_CONV3S2)
@@ -570,14 +591,17 @@ extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t
     ide3d_modconv_params p{};
     p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w; p.k = k; p.mode = mode; p.w_batch_stride = per_image_weights ? 1 : 0;
     if (check_modconv(p) != IDE3D_OK) return -1;
+    p.x = nullptr;                               // alignment of the real tensor is unknown here: size for the larger plan
     ConvPlan pl; plan_conv(p, pl);
+    ConvPlan pf; plan_conv(flatten_pointwise(p), pf);
+    if (pf.partial_floats > pl.partial_floats) pl.partial_floats = pf.partial_floats;
     return (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(pp != nullptr, "modconv2d: null params");
-    const ide3d_modconv_params& p = *pp;
+    const ide3d_modconv_params p = flatten_pointwise(*pp);
     IDE3D_CHECK_ARG(p.x && p.w && p.y && p.workspace, "modconv2d: null tensor / workspace pointer");
     int rc = check_modconv(p);
     if (rc) return rc;

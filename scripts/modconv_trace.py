@@ -1,5 +1,5 @@
 """Cycles one wave of the convolution kernel spends per phase of its K loop (library built with
-`make EXTRA=-DIDE3D_MC_TRACE`).  usage: python scripts/modconv_trace.py [tconv|conv] cin cout res"""
+`make EXTRA=-DIDE3D_MC_TRACE`).  usage: python scripts/modconv_trace.py [tconv|conv|heads] cin cout res [images]"""
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'ide-3d_amd'))
@@ -11,7 +11,10 @@ g = torch.Generator().manual_seed(0)
 n = 4
 x = torch.randn(n, cin, res, res, generator=g).to(dev); w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
 s = (torch.randn(n, cin, generator=g) + 1).to(dev); d = torch.rand(n, cout, generator=g).to(dev)
-if kind == 'tconv':
+if kind == 'heads':          # per-image 1x1 weights (the folded RGB + seg heads), bias, clamp
+    w = torch.randn(n, cout, cin, 1, 1, generator=g).to(dev); b = torch.randn(cout, generator=g).to(dev)
+    f = lambda: hip_plugin.ModconvPlugin.modconv2d(x, w, None, None, None, 0.0, b, 1, 0.0, 1.0, 256.0)
+elif kind == 'tconv':
     f = lambda: hip_plugin.ModconvPlugin.modconv2d(x, w, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
 else:
     f = lambda: hip_plugin.ModconvPlugin.modconv2d(x, w, s, d, None, 0.0, None, 3, 0.2, math.sqrt(2), -1.0)
