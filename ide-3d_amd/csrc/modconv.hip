@@ -47,6 +47,12 @@ __device__ unsigned long long g_mc_dbg[256];
 #define IDE3D_MC_TS(k)
 #endif
 
+#ifdef IDE3D_MC_NT
+#define IDE3D_MC_STORE(ptr, v) __builtin_nontemporal_store(v, ptr)
+#else
+#define IDE3D_MC_STORE(ptr, v) (*(ptr) = (v))
+#endif
+
 enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3, MODE_CONV3S2 = 4 };
 
 template <int MODE> struct ModeCfg;
@@ -171,6 +177,9 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
                                              const ConvGeom& g, float* s_w, float* s_x, int mb, int tl, int grp, int split, int cls,
                                              int tiles_x) {
     using K = McCfg<MODE, BIG, TI, PH, PW>;
+#ifdef IDE3D_MC_TRACE
+    const unsigned long long mc_t0 = __builtin_readcyclecounter();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / K::WN, wn = wid % K::WN;
     const int half = lane >> 5, l32 = lane & 31;
@@ -309,6 +318,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     __syncthreads();
 #ifdef IDE3D_MC_TRACE
     mc_last = __builtin_readcyclecounter();
+    const unsigned long long mc_prologue = mc_last - mc_t0;
 #endif
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
@@ -390,13 +400,22 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     }
 
 #ifdef IDE3D_MC_TRACE
-    if (blockIdx.x == 100 && threadIdx.x == 0) {
-        for (int k = 0; k < 6; ++k) g_mc_dbg[k] = mc_acc[k];
-        g_mc_dbg[7] = (unsigned long long)(c_end - c_begin);
-    }
+    const unsigned long long mc_t1 = __builtin_readcyclecounter();
 #endif
     // ---- epilogue ----
     const bool raw = (g.split_k > 1);
+    // Demodulation coefficients and biases of this block's BM output channels go to LDS first (the K loop has finished with
+    // s_w): a lane's 16 x MTW accumulator rows are 16 x MTW different channels, and one global load per row in front of each
+    // store exposes its latency that many times (measured: the epilogue took as long as 7 - 60 K chunks).
+    float* const s_dm = s_w;                       // [TI][BM]
+    float* const s_bi = s_w + TI * K::BM;          // [BM]
+    for (int e = tid; e < TI * K::BM; e += 256) {
+        const int rl = e % K::BM, co = mb * K::BM + rl, n = min(n0 + e / K::BM, p.n - 1);
+        s_dm[e] = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
+        if (e < K::BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
+    }
+    __syncthreads();
+    const bool has_d = !raw && p.dcoefs, has_b = !raw && p.bias;
 #pragma unroll
     for (int q = 0; q < K::NCLS; ++q)
 #pragma unroll
@@ -416,21 +435,29 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int co = mb * K::BM + (wm * K::MTW + i) * 32 + row;
+                const int rl = (wm * K::MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
+                const int co = mb * K::BM + rl;
                 if (co >= p.cout) continue;
                 float v = acc[q][i][j][r];
                 if (!raw) {
-                    if (p.dcoefs) v *= p.dcoefs[(int64_t)n * p.cout + co];
+                    if (has_d) v *= s_dm[ti * K::BM + rl];
                     v += nz;
-                    if (p.bias) v += p.bias[co];
+                    if (has_b) v += s_bi[rl];
                     if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
                     v *= p.gain;
                     if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
                 }
-                dst[(((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox] = v;
+                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, v);
             }
     }
+#ifdef IDE3D_MC_TRACE
+    if (blockIdx.x == 100 && threadIdx.x == 0) {
+        for (int k = 0; k < 6; ++k) g_mc_dbg[k] = mc_acc[k];
+        g_mc_dbg[7] = (unsigned long long)(c_end - c_begin);
+        g_mc_dbg[8] = mc_prologue;
+        g_mc_dbg[9] = __builtin_readcyclecounter() - mc_t1;      // epilogue: issue of the stores (not their completion)
+    }
+#endif
 }
 
 // ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
@@ -528,9 +555,14 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
     if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
+    // 32-pixel tile rows for the plain 3x3 convolution: an MFMA N tile is then one row, i.e. every epilogue store covers
+    // two 128-byte runs instead of four 64-byte ones (the epilogue is 10-20 % of a convolution launch)
+    if (pl.mode == MODE_CONV3 && gw[0] >= 32 && gw[0] % 32 == 0 && !getenv("IDE3D_MODCONV_NO_WIDE")) {
+        if (pl.tile == 3) pl.tile = 6; else if (pl.tile == 0) pl.tile = 7;
+    }
     if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
-    static const int TIv[6] = {1, 2, 8, 1, 1, 1}, PHv[6] = {8, 8, 4, 16, 4, 1}, PWv[6] = {16, 8, 4, 16, 16, 128};
+    static const int TIv[8] = {1, 2, 8, 1, 1, 1, 1, 1}, PHv[8] = {8, 8, 4, 16, 4, 1, 8, 4}, PWv[8] = {16, 8, 4, 16, 16, 128, 32, 32};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -564,6 +596,12 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     if (pl.tile == 5) {
         if constexpr (MODE == MODE_CONV1)
             hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 1, 128>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+    }
+    else if (pl.tile == 6 || pl.tile == 7) {
+        if constexpr (MODE == MODE_CONV3) {
+            if constexpr (BIG == 1) { if (pl.tile == 6) { hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 32>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g); return; } }
+            hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 32>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+        }
     }
     else if (pl.tile == 0) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);

@@ -27,4 +27,4 @@ assert lib.ide3d_debug_mc(buf) == 0
 chunks = max(int(buf[7]), 1)
 names = ('loop', 'patch loads issue', 'operand reads + MFMA', 'commit + vmcnt(0)', 'barrier', 'weight DMA issue')
 print(f'{kind} {cin}->{cout} @{res}: {chunks} chunks; cycles per chunk: ' +
-      ', '.join(f'{nm} {buf[k] / chunks:.0f}' for k, nm in enumerate(names)) + f'; total {sum(buf[:6]) / chunks:.0f}')
+      ', '.join(f'{nm} {buf[k] / chunks:.0f}' for k, nm in enumerate(names)) + f'; prologue (plan + first chunk) {buf[8]}, epilogue issue {buf[9]}')
