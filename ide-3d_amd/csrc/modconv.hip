@@ -416,6 +416,72 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     }
     __syncthreads();
     const bool has_d = !raw && p.dcoefs, has_b = !raw && p.bias;
+    float* const dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
+    auto finish = [&](float v, int ti, int rl, float nz) {      // everything between the accumulator and the stored value
+        if (!raw) {
+            if (has_d) v *= s_dm[ti * K::BM + rl];
+            v += nz;
+            if (has_b) v += s_bi[rl];
+            if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
+            v *= p.gain;
+            if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+        }
+        return v;
+    };
+    // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores.  The finished values of
+    // RR channel rows go through a wave-private LDS tile ([row][pixel], the two x-parity classes of the all-class
+    // transposed convolution interleaved) and leave as 16-byte stores of 4 consecutive output pixels.
+    constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = K::NCLS / QX;
+    constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
+    constexpr int AVAIL = 2 * K::LDS_W - (TI + 1) * K::BM;
+    constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= 4 * 32 * TP) ? 32 : (AVAIL >= 4 * 16 * TP) ? 16 : (AVAIL >= 4 * 8 * TP) ? 8 : 0;
+    if constexpr (RR > 0) {
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        float* const T = s_w + (TI + 1) * K::BM + wid * (RR * TP);
+#pragma unroll
+        for (int qy = 0; qy < QY; ++qy)
+#pragma unroll
+        for (int j = 0; j < K::NTW; ++j) {
+            const int pbase = (wn * K::NTW + j) * 32;
+            float nz[QX];
+#pragma unroll
+            for (int qx = 0; qx < QX; ++qx) {
+                const int pix = pbase + l32, rem = pix % (PH * PW);
+                const int gy = y0 + rem / PW, gx = x0 + rem % PW;
+                const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx + qx : gx;
+                nz[qx] = (!raw && p.noise && oy < g.oh && ox < g.ow) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < K::MTW; ++i)
+#pragma unroll
+            for (int g0 = 0; g0 < 4; g0 += RR / 8) {
+                const int ti_w = (pbase + l32) / (PH * PW);
+#pragma unroll
+                for (int qx = 0; qx < QX; ++qx)
+#pragma unroll
+                    for (int gg = 0; gg < RR / 8; ++gg)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int rowl = gg * 8 + rr + 4 * half;
+                            const int rl = (wm * K::MTW + i) * 32 + g0 * 8 + rowl;
+                            T[rowl * TP + l32 * QX + qx] = finish(acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr], ti_w, rl, nz[qx]);
+                        }
+#pragma unroll
+                for (int k = 0; k < RR * (TW / 4) / 64; ++k) {
+                    const int idx = lane + 64 * k, rowl = idx / (TW / 4), c4 = idx % (TW / 4);
+                    const f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
+                    const int co = mb * K::BM + (wm * K::MTW + i) * 32 + g0 * 8 + rowl;
+                    const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
+                    const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
+                    const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
+                    if (co >= p.cout || n >= p.n || oy >= g.oh || ox >= g.ow) continue;
+                    float* o = dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox;
+                    if (ox + 3 < g.ow) *reinterpret_cast<f32x4u*>(o) = v4;
+                    else { for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e]; }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < K::NCLS; ++q)
 #pragma unroll
@@ -424,13 +490,10 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         const int ti = pix / (PH * PW), rem = pix % (PH * PW);
         const int n = n0 + ti;
         const int gy = y0 + rem / PW, gx = x0 + rem % PW;              // (class-)grid coordinates
-        const int qy = (MODE == MODE_TCONV3A) ? (q >> 1) : cpy, qx = (MODE == MODE_TCONV3A) ? (q & 1) : cpx;
-        const int oy = (MODE == MODE_TCONV3 || MODE == MODE_TCONV3A) ? 2 * gy + qy : gy;
-        const int ox = (MODE == MODE_TCONV3 || MODE == MODE_TCONV3A) ? 2 * gx + qx : gx;
+        const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy, ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
         const bool ok = n < p.n && oy < g.oh && ox < g.ow;
         if (!ok) continue;
         const float nz = (!raw && p.noise) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
-        float* dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
@@ -438,17 +501,9 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
                 const int rl = (wm * K::MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
                 const int co = mb * K::BM + rl;
                 if (co >= p.cout) continue;
-                float v = acc[q][i][j][r];
-                if (!raw) {
-                    if (has_d) v *= s_dm[ti * K::BM + rl];
-                    v += nz;
-                    if (has_b) v += s_bi[rl];
-                    if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
-                    v *= p.gain;
-                    if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-                }
-                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, v);
+                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, finish(acc[q][i][j][r], ti, rl, nz));
             }
+    }
     }
 #ifdef IDE3D_MC_TRACE
     if (blockIdx.x == 100 && threadIdx.x == 0) {
@@ -555,14 +610,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
     if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
-    // 32-pixel tile rows for the plain 3x3 convolution: an MFMA N tile is then one row, i.e. every epilogue store covers
-    // two 128-byte runs instead of four 64-byte ones (the epilogue is 10-20 % of a convolution launch)
-    if (pl.mode == MODE_CONV3 && gw[0] >= 32 && gw[0] % 32 == 0 && !getenv("IDE3D_MODCONV_NO_WIDE")) {
-        if (pl.tile == 3) pl.tile = 6; else if (pl.tile == 0) pl.tile = 7;
-    }
     if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
-    static const int TIv[8] = {1, 2, 8, 1, 1, 1, 1, 1}, PHv[8] = {8, 8, 4, 16, 4, 1, 8, 4}, PWv[8] = {16, 8, 4, 16, 16, 128, 32, 32};
+    static const int TIv[6] = {1, 2, 8, 1, 1, 1}, PHv[6] = {8, 8, 4, 16, 4, 1}, PWv[6] = {16, 8, 4, 16, 16, 128};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -596,12 +646,6 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     if (pl.tile == 5) {
         if constexpr (MODE == MODE_CONV1)
             hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 1, 128>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
-    }
-    else if (pl.tile == 6 || pl.tile == 7) {
-        if constexpr (MODE == MODE_CONV3) {
-            if constexpr (BIG == 1) { if (pl.tile == 6) { hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 32>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g); return; } }
-            hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 32>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
-        }
     }
     else if (pl.tile == 0) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
     else if (pl.tile == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 2, 8, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
