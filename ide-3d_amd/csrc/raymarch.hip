@@ -86,13 +86,33 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ pb, co
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
         const int ch = 4 * (g + 4 * ci);
-        const float4 a0 = gather_plane_cl(pb + ch, t[0]);
-        const float4 a1 = gather_plane_cl(pb + C + ch, t[1]);
-        const float4 a2 = gather_plane_cl(pb + 2 * C + ch, t[2]);
-        f[4 * ci + 0] = (a0.x + a1.x) + a2.x;
-        f[4 * ci + 1] = (a0.y + a1.y) + a2.y;
-        f[4 * ci + 2] = (a0.z + a1.z) + a2.z;
-        f[4 * ci + 3] = (a0.w + a1.w) + a2.w;
+        // all twelve 16-byte tap loads of this channel slice are issued before the first one is consumed: left to itself
+        // the compiler loads a plane's four taps, waits, blends, and so exposes the L2 latency three times per slice
+        float4 v[3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const float* base = pb + pl * C + ch;
+            v[pl][0] = ld4(base + t[pl].o00); v[pl][1] = ld4(base + t[pl].o01);
+            v[pl][2] = ld4(base + t[pl].o10); v[pl][3] = ld4(base + t[pl].o11);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(v[pl][k].x), "+v"(v[pl][k].y), "+v"(v[pl][k].z), "+v"(v[pl][k].w));
+        float4 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = f4_fma(v[pl][0], t[pl].w00, acc);
+            acc = f4_fma(v[pl][1], t[pl].w01, acc);
+            acc = f4_fma(v[pl][2], t[pl].w10, acc);
+            acc = f4_fma(v[pl][3], t[pl].w11, acc);
+            a[pl] = acc;
+        }
+        f[4 * ci + 0] = (a[0].x + a[1].x) + a[2].x;
+        f[4 * ci + 1] = (a[0].y + a[1].y) + a[2].y;
+        f[4 * ci + 2] = (a[0].z + a[1].z) + a[2].z;
+        f[4 * ci + 3] = (a[0].w + a[1].w) + a[2].w;
     }
 }
 
