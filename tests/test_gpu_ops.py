@@ -410,7 +410,10 @@ def test_sample_pdf_kernel(golden, gpu_device):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k', [(2, 8, 16, 4, 4, 3), (1, 20, 150, 19, 33, 3), (3, 32, 96, 16, 16, 1), (2, 64, 3, 40, 24, 1),
-                                            (1, 128, 128, 32, 32, 3), (2, 6, 19, 9, 70, 1)])
+                                            (1, 128, 128, 32, 32, 3), (2, 6, 19, 9, 70, 1),
+                                            # flattened 1x1 tiles with a ragged last tile and rows that are not multiples of 4;
+                                            # multi-image tiles (2x8x8, 8x4x4) with a ragged image group: partial 16-byte epilogue stores
+                                            (2, 24, 40, 10, 14, 1), (5, 16, 48, 6, 6, 3), (9, 8, 40, 3, 5, 3), (1, 4, 200, 7, 129, 3)])
 def test_modconv2d_against_conv2d(gpu_device, n, cin, cout, h, w, k):
     from torch_utils import hip_plugin
     g = torch.Generator().manual_seed(12)
