@@ -415,22 +415,22 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         if (e < K::BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
     }
     __syncthreads();
-    const bool has_d = !raw && p.dcoefs, has_b = !raw && p.bias;
     float* const dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
-    auto finish = [&](float v, int ti, int rl, float nz) {      // everything between the accumulator and the stored value
-        if (!raw) {
-            if (has_d) v *= s_dm[ti * K::BM + rl];
-            v += nz;
-            if (has_b) v += s_bi[rl];
-            if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
-            v *= p.gain;
-            if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-        }
-        return v;
+    // Branch-free finish: absent terms are identities (d = 1, b = 0 in LDS; slope 1 = linear; clamp +inf; split-K partials
+    // take all of them), so the 128 values of a lane do not cost four uniform branches each.
+    const float e_alpha = (!raw && p.act == 3) ? p.alpha : 1.f, e_gain = raw ? 1.f : p.gain;
+    const float e_clamp = (!raw && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+    const float e_nstr = (!raw && p.noise) ? p.noise_strength : 0.f;
+    auto finish = [&](float v, float d, float nz, float bb) {
+        v *= d; v += nz; v += bb;
+        v = (v > 0.f) ? v : v * e_alpha;
+        v *= e_gain;
+        return fminf(fmaxf(v, -e_clamp), e_clamp);
     };
-    // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores.  The finished values of
-    // RR channel rows go through a wave-private LDS tile ([row][pixel], the two x-parity classes of the all-class
-    // transposed convolution interleaved) and leave as 16-byte stores of 4 consecutive output pixels.
+    // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores and 16 different
+    // demodulation / bias values.  RR channel rows of raw accumulators go through a wave-private LDS tile ([row][pixel], the
+    // two x-parity classes of the all-class transposed convolution interleaved); a lane then takes 4 consecutive output
+    // pixels of ONE channel, finishes them (one d / b pair, one 16-byte noise load) and stores 16 bytes.
     constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = K::NCLS / QX;
     constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
     constexpr int AVAIL = 2 * K::LDS_W - (TI + 1) * K::BM;
@@ -443,41 +443,39 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
 #pragma unroll
         for (int j = 0; j < K::NTW; ++j) {
             const int pbase = (wn * K::NTW + j) * 32;
-            float nz[QX];
-#pragma unroll
-            for (int qx = 0; qx < QX; ++qx) {
-                const int pix = pbase + l32, rem = pix % (PH * PW);
-                const int gy = y0 + rem / PW, gx = x0 + rem % PW;
-                const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx + qx : gx;
-                nz[qx] = (!raw && p.noise && oy < g.oh && ox < g.ow) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
-            }
 #pragma unroll
             for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
             for (int g0 = 0; g0 < 4; g0 += RR / 8) {
-                const int ti_w = (pbase + l32) / (PH * PW);
 #pragma unroll
                 for (int qx = 0; qx < QX; ++qx)
 #pragma unroll
                     for (int gg = 0; gg < RR / 8; ++gg)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int rowl = gg * 8 + rr + 4 * half;
-                            const int rl = (wm * K::MTW + i) * 32 + g0 * 8 + rowl;
-                            T[rowl * TP + l32 * QX + qx] = finish(acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr], ti_w, rl, nz[qx]);
-                        }
+                        for (int rr = 0; rr < 4; ++rr)
+                            T[(gg * 8 + rr + 4 * half) * TP + l32 * QX + qx] = acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr];
 #pragma unroll
                 for (int k = 0; k < RR * (TW / 4) / 64; ++k) {
                     const int idx = lane + 64 * k, rowl = idx / (TW / 4), c4 = idx % (TW / 4);
-                    const f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
-                    const int co = mb * K::BM + (wm * K::MTW + i) * 32 + g0 * 8 + rowl;
+                    f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
+                    const int rl = (wm * K::MTW + i) * 32 + g0 * 8 + rowl, co = mb * K::BM + rl;
                     const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
                     const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
                     const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
                     if (co >= p.cout || n >= p.n || oy >= g.oh || ox >= g.ow) continue;
-                    float* o = dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox;
-                    if (ox + 3 < g.ow) *reinterpret_cast<f32x4u*>(o) = v4;
-                    else { for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e]; }
+                    const float d = s_dm[ti * K::BM + rl], bb = s_bi[rl];
+                    const int64_t pofs = (int64_t)oy * g.ow + ox;
+                    float* o = dst + ((int64_t)n * p.cout + co) * ((int64_t)g.oh * g.ow) + pofs;
+                    if (ox + 3 < g.ow) {
+                        f32x4u nz = {0.f, 0.f, 0.f, 0.f};
+                        if (e_nstr != 0.f) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
+                        *reinterpret_cast<f32x4u*>(o) = v4;
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (ox + e < g.ow) o[e] = finish(v4[e], d, (e_nstr != 0.f) ? p.noise[pofs + e] * e_nstr : 0.f, bb);
+                    }
                 }
             }
         }
@@ -493,7 +491,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy, ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
         const bool ok = n < p.n && oy < g.oh && ox < g.ow;
         if (!ok) continue;
-        const float nz = (!raw && p.noise) ? p.noise[oy * g.ow + ox] * p.noise_strength : 0.f;
+        const float nz = (e_nstr != 0.f) ? p.noise[oy * g.ow + ox] * e_nstr : 0.f;
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
@@ -501,7 +499,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
                 const int rl = (wm * K::MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
                 const int co = mb * K::BM + rl;
                 if (co >= p.cout) continue;
-                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, finish(acc[q][i][j][r], ti, rl, nz));
+                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, finish(acc[q][i][j][r], s_dm[ti * K::BM + rl], nz, s_bi[rl]));
             }
     }
     }
