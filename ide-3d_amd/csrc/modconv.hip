@@ -443,6 +443,19 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
 #pragma unroll
         for (int j = 0; j < K::NTW; ++j) {
             const int pbase = (wn * K::NTW + j) * 32;
+            // what a lane stores depends on (row, pixel group); the pixel group c4 = lane % (TW / 4) is the same in every round
+            const int c4 = lane % (TW / 4), row0 = lane / (TW / 4);
+            const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
+            const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
+            const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
+            const bool px_ok = n < p.n && oy < g.oh && ox < g.ow, full = ox + 3 < g.ow;
+            const int64_t pofs = (int64_t)oy * g.ow + ox;
+            f32x4u nz = {0.f, 0.f, 0.f, 0.f};
+            if (e_nstr != 0.f && px_ok) {
+                if (full) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
+                else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[pofs + e] * e_nstr;
+            }
+            float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * g.ow) + pofs;
 #pragma unroll
             for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
@@ -456,26 +469,16 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
                             T[(gg * 8 + rr + 4 * half) * TP + l32 * QX + qx] = acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr];
 #pragma unroll
                 for (int k = 0; k < RR * (TW / 4) / 64; ++k) {
-                    const int idx = lane + 64 * k, rowl = idx / (TW / 4), c4 = idx % (TW / 4);
+                    const int rowl = row0 + k * (256 / TW);
                     f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
                     const int rl = (wm * K::MTW + i) * 32 + g0 * 8 + rowl, co = mb * K::BM + rl;
-                    const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
-                    const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
-                    const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
-                    if (co >= p.cout || n >= p.n || oy >= g.oh || ox >= g.ow) continue;
+                    if (!px_ok || co >= p.cout) continue;
                     const float d = s_dm[ti * K::BM + rl], bb = s_bi[rl];
-                    const int64_t pofs = (int64_t)oy * g.ow + ox;
-                    float* o = dst + ((int64_t)n * p.cout + co) * ((int64_t)g.oh * g.ow) + pofs;
-                    if (ox + 3 < g.ow) {
-                        f32x4u nz = {0.f, 0.f, 0.f, 0.f};
-                        if (e_nstr != 0.f) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
-                        *reinterpret_cast<f32x4u*>(o) = v4;
-                    } else {
-                        for (int e = 0; e < 4; ++e)
-                            if (ox + e < g.ow) o[e] = finish(v4[e], d, (e_nstr != 0.f) ? p.noise[pofs + e] * e_nstr : 0.f, bb);
-                    }
+                    for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
+                    float* o = o_px + (int64_t)co * ((int64_t)g.oh * g.ow);
+                    if (full) *reinterpret_cast<f32x4u*>(o) = v4;
+                    else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e];
                 }
             }
         }
