@@ -47,12 +47,6 @@ __device__ unsigned long long g_mc_dbg[256];
 #define IDE3D_MC_TS(k)
 #endif
 
-#ifdef IDE3D_MC_NT
-#define IDE3D_MC_STORE(ptr, v) __builtin_nontemporal_store(v, ptr)
-#else
-#define IDE3D_MC_STORE(ptr, v) (*(ptr) = (v))
-#endif
-
 enum { MODE_CONV3 = 0, MODE_CONV1 = 1, MODE_TCONV3 = 2, MODE_TCONV3A = 3, MODE_CONV3S2 = 4 };
 
 template <int MODE> struct ModeCfg;
@@ -502,7 +496,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
                 const int rl = (wm * K::MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
                 const int co = mb * K::BM + rl;
                 if (co >= p.cout) continue;
-                IDE3D_MC_STORE(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox, finish(acc[q][i][j][r], s_dm[ti * K::BM + rl], nz, s_bi[rl]));
+                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = finish(acc[q][i][j][r], s_dm[ti * K::BM + rl], nz, s_bi[rl]);
             }
     }
     }
@@ -574,18 +568,29 @@ struct ConvPlan {
     ConvGeom g;
 };
 
+// Developer knobs (read once): IDE3D_MODCONV_NO_FLAT / _NO_TCONV3A switch the flattened 1x1 tiles / the all-class
+// transposed kernel off, IDE3D_MODCONV_TILE forces a pixel tile (0..3), IDE3D_MODCONV_DEBUG = 1 drops the staging after
+// the first chunk (timing experiments; wrong results).
+struct McEnv { bool no_flat, no_allcls; int tile, debug; };
+static const McEnv& mc_env() {
+    static const McEnv e = {getenv("IDE3D_MODCONV_NO_FLAT") != nullptr, getenv("IDE3D_MODCONV_NO_TCONV3A") != nullptr,
+                            getenv("IDE3D_MODCONV_TILE") ? atoi(getenv("IDE3D_MODCONV_TILE")) : -1,
+                            getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0};
+    return e;
+}
+
 // A 1x1 convolution does not see the image shape: h x w is treated as one row, tiled in runs of 128 pixels whose patch
 // rows are contiguous in memory (16-byte staging, 128-byte output runs).  Needs 16-byte aligned rows.
 static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
     ide3d_modconv_params p = in;
     const int64_t hw = (int64_t)p.h * p.w_;
-    if (p.k == 1 && p.mode == 0 && hw % 4 == 0 && hw >= 128 && ((uintptr_t)p.x % 16) == 0 && !getenv("IDE3D_MODCONV_NO_FLAT")) { p.h = 1; p.w_ = (int)hw; }
+    if (p.k == 1 && p.mode == 0 && hw % 4 == 0 && hw >= 128 && ((uintptr_t)p.x % 16) == 0 && !mc_env().no_flat) { p.h = 1; p.w_ = (int)hw; }
     return p;
 }
 
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
-    const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !getenv("IDE3D_MODCONV_NO_TCONV3A");
+    const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
@@ -610,7 +615,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         const int64_t blocks256 = (int64_t)pl.mblocks * cdiv(gh[0], 16) * cdiv(gw[0], 16) * p.n * ((pl.mode == MODE_TCONV3) ? 4 : 1);
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
-    if (const char* e = getenv("IDE3D_MODCONV_TILE")) { const int t = atoi(e); if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
+    if (mc_env().tile >= 0) { const int t = mc_env().tile; if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
     if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
     static const int TIv[6] = {1, 2, 8, 1, 1, 1}, PHv[6] = {8, 8, 4, 16, 4, 1}, PWv[6] = {16, 8, 4, 16, 16, 128};
@@ -622,7 +627,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     }
     g.img_groups = cdiv(p.n, TIv[pl.tile]);
     g.mblocks = pl.mblocks; g.cchunks = pl.cchunks; g.oh = pl.oh; g.ow = pl.ow;
-    g.debug = getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0;
+    g.debug = mc_env().debug;
     const int64_t base_blocks = (int64_t)g.mblocks * g.tile_base[4] * g.img_groups;
     int split = 1;
     if (base_blocks < 512 && pl.cchunks >= 8) {
