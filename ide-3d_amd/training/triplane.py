@@ -26,6 +26,7 @@ parity statements are "this path vs the CPU oracle with the same spec and weight
 
 import dataclasses
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -270,6 +271,7 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
             setattr(self, f'vb{res}', block)
 
         self.renderer = TriplaneRenderer(spec)
+        self.style_prefetch = True        # GPU inference: style kernels on a side stream (networks.prefetch_styles)
 
         widths = spec.sr_widths()
         cin = spec.feature_channels
@@ -327,6 +329,13 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         render_params = dict(render_params or {})
         voxel_ws, block_ws = self.split_ws(ws)
         block_kwargs = dict(noise_mode=noise_mode, force_fp32=True)
+        prefetch = getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled() and not os.environ.get('IDE3D_NO_STYLE_PREFETCH')
+        if prefetch:
+            # all style / demodulation / head-folding launches of this pass go to a side stream (they depend only on ws)
+            side = networks.side_stream(ws.device)
+            todo = [] if cached_planes is not None else [(getattr(self, f'vb{r}'), w) for r, w in zip(self.voxel_block_resolutions, voxel_ws)]
+            todo += [(getattr(self, f'b{r}'), w) for r, w in zip(self.block_resolutions, block_ws)]
+            networks.prefetch_styles(todo, side)
         if cached_planes is not None:
             img_v, seg_v = cached_planes
         else:
@@ -338,6 +347,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
             nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter,
             hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
         img, seg = self.superres(feat, block_ws, **block_kwargs)
+        if prefetch:
+            networks.finish_prefetch(side)
         img_raw = feat[:, :self.img_channels]
         if return_dict:
             return dict(image=img, image_seg=seg, image_raw=img_raw, image_depth=depth, planes=(img_v, seg_v))
