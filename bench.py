@@ -146,6 +146,13 @@ def main():
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write banners to file descriptor 1 (RCCL prints its
+    # version / host / library path at communicator creation), so fd 1 is pointed at stderr for the whole run and the
+    # JSON line goes to a duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -230,7 +237,7 @@ def main():
             out['roofline'] = bench_gather(device)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
