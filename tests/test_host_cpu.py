@@ -239,6 +239,42 @@ def test_hierarchical_pass_cpu(golden):
     assert_close(out['image_depth'], want[1], rtol=1e-4, atol=1e-5, what='hierarchical through G.synthesis')
 
 
+def test_style_plan_matches_block_forward(golden):
+    """`networks._style_plan` (what the side-stream style prefetch enumerates) lists exactly the (layer, w) pairs a block's
+    forward consumes, in order — checked by recording the real calls of a CPU forward pass."""
+    from training import networks
+    G, cfg, a = load_golden_generator(golden)
+    syn = G.synthesis
+    ws = t(a['out_ws'])
+    voxel_ws, block_ws = syn.split_ws(ws)
+    planned = []
+    for res, w in list(zip(syn.voxel_block_resolutions, voxel_ws)):
+        planned += [(kind, id(mod.affine) if kind == 'conv' else id(mod.torgb.affine), wl.data_ptr())
+                    for kind, mod, wl in networks._style_plan(getattr(syn, f'vb{res}'), w)]
+    for res, w in list(zip(syn.block_resolutions, block_ws)):
+        planned += [(kind, id(mod.affine) if kind == 'conv' else id(mod.torgb.affine), wl.data_ptr())
+                    for kind, mod, wl in networks._style_plan(getattr(syn, f'b{res}'), w)]
+    seen = []
+    real, real_heads = networks._styles_and_dcoefs, networks._dual_head
+    conv_affines = {p_[1] for p_ in planned if p_[0] == 'conv'}
+
+    def spy(affine, w, weight, demodulate):
+        if id(affine) in conv_affines:
+            seen.append(('conv', id(affine), w.data_ptr()))
+        return real(affine, w, weight, demodulate)
+
+    def spy_heads(x, torgb, toseg, w):
+        seen.append(('heads', id(torgb.affine), w.data_ptr()))
+        return real_heads(x, torgb, toseg, w)
+    networks._styles_and_dcoefs, networks._dual_head = spy, spy_heads
+    try:
+        with torch.no_grad():
+            syn(ws, c=t(a['in_c']), noise_mode='const', ray_jitter=t(a['in_jitter']))
+    finally:
+        networks._styles_and_dcoefs, networks._dual_head = real, real_heads
+    assert planned == seen
+
+
 def test_shape_extraction_cpu(golden):
     """extract_shapes.py lattice (bit-exact vs the reference-run fixture) and chunked density query == oracle (tiny G)."""
     from training import shape_extraction as se, triplane
