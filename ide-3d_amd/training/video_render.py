@@ -11,7 +11,7 @@ time (`kind='cubic'`, `wraps` periodic copies), one look-at camera per frame swe
 """
 
 import math
-from typing import Iterator, Sequence, Tuple
+from typing import Iterable, Iterator, Sequence, Tuple
 
 import numpy as np
 import scipy.interpolate
@@ -95,3 +95,54 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
         else:
             cell_frames = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
         yield layout_u8(cell_frames, grid_w, grid_h)
+
+
+# ---- dependency-free video sink --------------------------------------------------------------------------------------
+# The reference encodes with imageio / libx264 (gen_videos.py:108,139), which is not installable here.  YUV4MPEG2 is the
+# uncompressed stream every encoder reads (`ffmpeg -i out.y4m out.mp4`, `mpv out.y4m`), needs no library and keeps the
+# colour conversion on the device that rendered the frame.
+
+def rgb_u8_to_yuv444(frame: torch.Tensor) -> torch.Tensor:
+    """uint8 [H, W, 3] RGB -> uint8 [3, H, W] planar Y'CbCr (BT.601, limited range, the integer matrix of ITU-T T.871 scaled to
+    16..235 / 16..240): Y = 16 + (66 R + 129 G + 25 B + 128) >> 8, Cb = 128 + (-38 R - 74 G + 112 B + 128) >> 8,
+    Cr = 128 + (112 R - 94 G - 18 B + 128) >> 8."""
+    assert frame.dtype == torch.uint8 and frame.ndim == 3 and frame.shape[2] == 3
+    rgb = frame.to(torch.int32)
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    y = 16 + ((66 * r + 129 * g + 25 * b + 128) >> 8)
+    cb = 128 + ((-38 * r - 74 * g + 112 * b + 128) >> 8)
+    cr = 128 + ((112 * r - 94 * g - 18 * b + 128) >> 8)
+    return torch.stack([y, cb, cr]).clamp_(0, 255).to(torch.uint8)
+
+
+def write_y4m(frames: Iterable[torch.Tensor], path: str, fps: int = 60) -> int:
+    """Write uint8 [H, W, 3] RGB frames (any device, e.g. what `gen_interp_frames` yields) as a YUV4MPEG2 4:4:4 stream.
+    Returns the number of frames written."""
+    count = 0
+    with open(path, 'wb') as f:
+        for frame in frames:
+            if count == 0:
+                h, w = int(frame.shape[0]), int(frame.shape[1])
+                f.write(f'YUV4MPEG2 W{w} H{h} F{int(fps)}:1 Ip A1:1 C444\n'.encode('ascii'))
+            assert tuple(frame.shape[:2]) == (h, w), 'all frames of a stream have one size'
+            f.write(b'FRAME\n')
+            f.write(rgb_u8_to_yuv444(frame).cpu().numpy().tobytes())
+            count += 1
+    return count
+
+
+def read_y4m(path: str):
+    """(header dict, uint8 array [frames, 3, H, W]) of a 4:4:4 stream written by `write_y4m` (tests, round trips)."""
+    with open(path, 'rb') as f:
+        head = f.readline().decode('ascii').split()
+        assert head[0] == 'YUV4MPEG2' and 'C444' in head
+        info = {t[0]: t[1:] for t in head[1:]}
+        w, h = int(info['W']), int(info['H'])
+        frames = []
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            assert line.startswith(b'FRAME')
+            frames.append(np.frombuffer(f.read(3 * h * w), dtype=np.uint8).reshape(3, h, w))
+    return info, np.stack(frames) if frames else np.zeros((0, 3, h, w), np.uint8)

@@ -374,6 +374,26 @@ def build_encoder(cfg):
     return encoders.Encoder(size=cfg['size'], n_latents=cfg['n_latents'], w_dim=cfg['w_dim'], add_dim=cfg['add_dim']).eval()
 
 
+def test_y4m_video_sink(tmp_path):
+    """Dependency-free video sink (training.video_render.write_y4m): header, frame count, BT.601 limited-range conversion
+    checked on the primaries and against the float definition."""
+    from training import video_render
+    g = torch.Generator().manual_seed(2)
+    frames = [torch.randint(0, 256, (6, 10, 3), generator=g, dtype=torch.uint8) for _ in range(3)]
+    frames[0][0, 0] = torch.tensor([255, 255, 255], dtype=torch.uint8); frames[0][0, 1] = torch.tensor([0, 0, 0], dtype=torch.uint8)
+    frames[0][0, 2] = torch.tensor([255, 0, 0], dtype=torch.uint8)
+    path = str(tmp_path / 'clip.y4m')
+    assert video_render.write_y4m(iter(frames), path, fps=30) == 3
+    info, yuv = video_render.read_y4m(path)
+    assert info['W'] == '10' and info['H'] == '6' and info['F'] == '30:1' and yuv.shape == (3, 3, 6, 10)
+    assert tuple(yuv[0, :, 0, 0]) == (235, 128, 128) and tuple(yuv[0, :, 0, 1]) == (16, 128, 128)      # white, black
+    assert tuple(yuv[0, :, 0, 2]) == (82, 90, 240)                                                     # red
+    rgb = torch.stack(frames).double()
+    m = torch.tensor([[65.481, 128.553, 24.966], [-37.797, -74.203, 112.0], [112.0, -93.786, -18.214]], dtype=torch.float64) / 255
+    want = (rgb @ m.t()) + torch.tensor([16.0, 128.0, 128.0], dtype=torch.float64)
+    assert float((torch.from_numpy(yuv.astype(np.float64)).permute(0, 2, 3, 1) - want).abs().max()) <= 1.0
+
+
 def test_encoders_cpu(golden):
     """HybridEncoder / Encoder (inversion/networks.py:1559-1665): same state-dict keys and (seeded) weights as the
     reference, same outputs as the reference run that produced the fixture."""
