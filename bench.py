@@ -1,20 +1,34 @@
 """bench.py — throughput of the IDE-3D render hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+With `--gpus N > 1` and no torch.distributed environment the script launches itself once per GPU
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per HIP device, RCCL);
+started under an external `torch.distributed.run` it uses the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it is given.
 
 A step = one pass of the hot path over one batch: `G.mapping` + `G.synthesis` (backbone -> tri-planes -> fused
 ray-marcher at 96 samples -> 64->512 super-resolution, RGB + 19-class seg) for 4 seeds on every rank, conversion to
 uint8 RGB|seg frames, and (N > 1) an RCCL gather of the uint8 frames to rank 0 — BASELINE.json config 2 per GPU,
 config 4's sharding across GPUs.  Random-init ide3d-ffhq-64-512 generator, synthetic latents, fp32.
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the tri-plane gather kernel (the kernel BASELINE's metric names): algorithmic bytes / HIP-event time
-  cpu_baseline  the CPU oracle ("port" of the reference's PyTorch CPU path) timed on the host cores, rank 0, N = 1 only
+
+Timing: W untimed warm-up steps, then `--blocks` (default 5) timed blocks of EXACTLY K steps, each bracketed by a barrier +
+`torch.cuda.synchronize()` on both sides, MAX over ranks per block; `value` / `ms_per_step` are the MEDIAN block (min / max
+are reported next to it: box-to-box and run-to-run spread is a few per cent).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline        the tri-plane gather kernel (the kernel BASELINE's metric names): algorithmic bytes / HIP-event time
+  roofline_extra  the same for every other hand-written kernel at its config-2 shape (scripts/kernel_rooflines.py), N = 1 only
+  cpu_baseline    the CPU oracle ("port" of the reference's PyTorch CPU path) timed on the host cores, rank 0, N = 1 only
+  parity_ok       after the timed region the SAME captured graph renders fixed inputs (seeds 0-3, fixed jitter) and the frames are
+                  compared with the oracle fixture tests/golden/bench_parity.npz (oracle/make_bench_parity.py); with the
+                  cpu_baseline leg on, the oracle frame computed there is compared live as well (`parity_live`)
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +41,40 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY = 6.29e12           # B/s, measured copy ceiling (same guide)
 FP32_MFMA_PEAK = 157.3e12    # FLOP/s
 BATCH = 4                    # seeds per rank per step (BASELINE config 2)
-PROFILE_ROUND = 'round1'
+PROFILE_ROUND = 'round2'
+YAWS = (-0.5, 0.0, 0.5, 0.25)
+PARITY_JITTER_SEED = 11      # = oracle/make_bench_parity.py
 
+
+# ---- launcher ----------------------------------------------------------------------------------------------------------------
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, env=None, python=sys.executable, capture=False):
+    """Run this script as `n` ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1, a free port).
+    Every rank inherits stdout, so rank 0's single JSON line is this process's output.  Returns the exit code
+    (and stdout when `capture`)."""
+    cmd = [python, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ if env is None else env)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: required by RCCL on this host driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    if capture:
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        return res.returncode, res.stdout
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- per-kernel figures ---------------------------------------------------------------------------------------------------------
 
 def gather_bytes(n_images, C=32, H=256, W=256, M=64 * 64 * 96, triplanes=1):
     """SURVEY.md §8(d) canonical formula: planes + coords + output, fp32."""
@@ -89,16 +133,23 @@ def bench_gather(device, iters=20, tiled=True):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
     # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
-    if os.path.isfile(pmc):
-        traffic = json.load(open(pmc)).get('hbm_traffic_bytes_per_launch')
-    return dict(kernel='triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel', bound='hbm', achieved=algo / (avg * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                frac=algo / (avg * 1e-3) / HBM_PEAK, traffic=traffic, bytes_per_launch=algo, avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
+    for rnd in (PROFILE_ROUND, 'round1'):
+        pmc = os.path.join(ROOT, 'profiles', rnd, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
+        if os.path.isfile(pmc):
+            traffic = json.load(open(pmc)).get('hbm_traffic_bytes_per_launch')
+            break
+    rate = algo / (avg * 1e-3)
+    return dict(kernel='triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel', bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9,
+                unit='GB/s', frac=rate / HBM_PEAK, frac_of_measured_copy_ceiling=rate / HBM_COPY, traffic=traffic, bytes_per_launch=algo,
+                avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 
 
-def cpu_baseline(budget_s=20.0):
-    """The CPU oracle (fp32 PyTorch-CPU port of the reference path) on the host cores: full-size generator, 1 seed per pass."""
+# ---- CPU baseline --------------------------------------------------------------------------------------------------------------
+
+def cpu_baseline(budget_s=20.0, parity_inputs=None):
+    """The CPU oracle (fp32 PyTorch-CPU port of the reference path) on the host cores: full-size generator, 1 seed per pass.
+    Returns (record, oracle output of parity image 0 or None)."""
     from oracle import fast_ops, generator as ogen, spec as ospec
     from training import triplane
     torch.manual_seed(0)
@@ -107,44 +158,94 @@ def cpu_baseline(budget_s=20.0):
     sp = ospec.Spec()
     c = triplane.camera_label(0.0)
     cond = triplane.conditioning_label()
-    # pick the thread count that is fastest on this host (a 256-thread pool is slower than 32 on small conv shapes)
-    probe_ws = ogen.mapping(sd, sp, torch.zeros(1, 512), cond, ops=fast_ops)
-    probe_feat = torch.randn(1, sp.feature_channels + sp.seg_channels, 64, 64)
-    best, cores = None, 1
-    for t in sorted({min(os.cpu_count() or 1, n) for n in (8, 16, 32, 64, 128, 256)}):
+
+    def one(seed, cam=c, jit=None, zrow=None):
+        z = torch.from_numpy(np.random.RandomState(seed).randn(1, 512)) if zrow is None else zrow
+        ws = ogen.mapping(sd, sp, z, cond, ops=fast_ops)
+        jit = torch.rand(1, 4096, 96) if jit is None else jit
+        return ogen.synthesis(sd, sp, ws, cam, jitter=jit, ops=fast_ops)
+
+    # thread count: probed on the WHOLE pass (mapping + backbone + renderer + super-resolution), one frame per candidate; a
+    # 256-thread pool is slower than a few dozen threads on these conv shapes
+    t_all = time.perf_counter()
+    best, cores, probes = None, 1, {}
+    for t in sorted({min(os.cpu_count() or 1, n) for n in (8, 16, 32, 64)}):
         torch.set_num_threads(t)
-        ogen.superres(sd, sp, probe_feat, probe_ws, 'const', fast_ops)
-        t0 = time.perf_counter(); ogen.superres(sd, sp, probe_feat, probe_ws, 'const', fast_ops); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); one(100 + t); dt = time.perf_counter() - t0
+        probes[t] = round(dt, 2)
         if best is None or dt < best:
             best, cores = dt, t
-    torch.set_num_threads(cores)
-
-    def one(seed):
-        z = torch.from_numpy(np.random.RandomState(seed).randn(1, 512))
-        ws = ogen.mapping(sd, sp, z, cond, ops=fast_ops)
-        jit = torch.rand(1, 4096, 96)
-        return ogen.synthesis(sd, sp, ws, c, jitter=jit, ops=fast_ops)
-
-    one(0)      # warm-up (allocator, thread pools)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(n + 1); n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 8:
+        if time.perf_counter() - t_all > budget_s:
             break
-    return dict(value=n / dt, unit='frames/s', cores=cores, kind='port',
-                sample=f'{n} full-size 512x512 RGB+seg frames (1 seed each, 96 samples, fp32 torch-CPU oracle, {cores} of {os.cpu_count()} host threads), {dt:.1f} s')
+    torch.set_num_threads(cores)
+    live = None
+    n, t0 = 0, time.perf_counter()
+    if parity_inputs is not None:      # the first timed frame doubles as the live parity reference (same work as any other frame)
+        z, cams, _cond, jit = parity_inputs
+        live = one(0, cam=cams[:1], jit=jit[:1], zrow=z[:1]); n = 1
+    while True:
+        dt = time.perf_counter() - t0
+        if (n >= 1 and dt > budget_s) or n >= 8:
+            break
+        one(n + 1); n += 1
+    dt = time.perf_counter() - t0
+    rec = dict(value=n / dt, unit='frames/s', cores=cores, kind='port',
+               note='fp32 torch-CPU restatement of the reference path (oracle/fast_ops.py + generator.py), golden-pinned to outputs of '
+                    '/root/reference run in the build container (tests/test_oracle_golden.py); /root/reference itself does not exist on this box',
+               thread_probe_s_per_frame=probes,
+               sample=f'{n} full-size 512x512 RGB+seg frames (1 seed each, 96 samples, fp32 torch-CPU oracle, {cores} of {os.cpu_count()} host threads), {dt:.1f} s')
+    return rec, live
 
+
+# ---- parity of the benchmarked graph -----------------------------------------------------------------------------------------------
+
+def parity_inputs():
+    """= oracle/make_bench_parity.parity_inputs (restated: the timed script never imports oracle/)."""
+    from training import triplane
+    z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in range(BATCH)]))
+    cams = torch.cat([triplane.camera_label(y) for y in YAWS])
+    cond = triplane.conditioning_label().repeat(BATCH, 1)
+    jit = torch.rand(BATCH, 4096, 96, generator=torch.Generator().manual_seed(PARITY_JITTER_SEED))
+    return z, cams, cond, jit
+
+
+def check_parity(render, device, tol=2e-3):
+    """Render the fixed parity inputs through `render` (the benchmarked callable) and compare with the oracle fixture."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'bench_parity.npz')
+    z, cams, cond, jit = parity_inputs()
+    img, seg = render(z.to(device), cond.to(device), cams.to(device), jit.to(device))
+    img, seg = img.float().cpu(), seg.float().cpu()
+    rec = dict(fixture='tests/golden/bench_parity.npz (CPU oracle, oracle/make_bench_parity.py)', tol_rel=tol)
+    if not os.path.isfile(path):
+        rec.update(ok=None, error='fixture missing')
+        return rec, (img, seg)
+    d = np.load(path)
+    errs = {'img': float((img[:, :, ::8, ::8] - torch.from_numpy(d['img'])).abs().max()) / float(d['scale_img']),
+            'seg': float((seg[:, :, ::16, ::16] - torch.from_numpy(d['seg'])).abs().max()) / float(d['scale_seg'])}
+    rec.update(ok=bool(max(errs.values()) <= tol), max_rel_err=errs, images=int(img.shape[0]))
+    return rec, (img, seg)
+
+
+# ---- main ------------------------------------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps steps each; the median block is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-roofline-extra', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='launcher / protocol self-test without a GPU: tiny generator on CPU tensors, gloo backend (tests/test_bench_launcher_cpu.py)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher, one rank per GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # The contract is ONE JSON line on stdout.  Native libraries write banners to file descriptor 1 (RCCL prints its
     # version / host / library path at communicator creation), so fd 1 is pointed at stderr for the whole run and the
@@ -156,87 +257,159 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    cpu = args.dry_run_cpu
     dist = None
     if world > 1 or os.environ.get('IDE3D_BENCH_FORCE_DIST'):     # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        if cpu:
+            dist.init_process_group(backend='gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if cpu:
+        device = torch.device('cpu')
+        torch.set_num_threads(2)
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU'
+        assert local_rank < torch.cuda.device_count(), f'rank {rank}: HIP device {local_rank} of {torch.cuda.device_count()} does not exist'
+        device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(device)
+    sync = (lambda: None) if cpu else torch.cuda.synchronize
 
-    from torch_utils import hip_plugin
     from training import triplane
     from training import distributed_render as dr
-    hip_plugin.load()     # hard error if the HIP library is missing
+    hip_plugin = None
+    if not cpu:
+        from torch_utils import hip_plugin
+        hip_plugin.load()     # hard error if the HIP library is missing
 
     torch.manual_seed(0)  # same random-init weights on every rank
-    G = triplane.TriPlaneGenerator().eval().to(device)
+    G = triplane.TriPlaneGenerator(triplane.tiny_spec() if cpu else None).eval().to(device)
     spec = G.spec
+    res = spec.img_resolution
     cond = triplane.conditioning_label(device).repeat(BATCH, 1)
-    yaws = [-0.5, 0.0, 0.5, 0.25]
-    cams = torch.cat([triplane.camera_label(y, device=device) for y in yaws])
+    cams = torch.cat([triplane.camera_label(y, device=device) for y in YAWS])
     palette = dr.palette_tensor(spec.seg_channels, device)
-    gathered = [torch.empty([BATCH, 512, 1024, 3], dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
+    gathered = [torch.empty([BATCH, res, 2 * res, 3], dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
 
     graphed = None
-    if args.graph:
+    if args.graph and not cpu:
         try:
             graphed = triplane.GraphedRenderer(G, BATCH, device)
         except Exception as e:      # capture is an optimisation, never a requirement
             print(f'[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             graphed = None
 
-    def step(i):
-        seeds = [(i * world + rank) * BATCH + j for j in range(BATCH)]
-        z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in seeds])).to(device)
+    def render(z, c_cond, c_cam, jitter=None):
+        """The benchmarked callable: new latents (and fresh stratified jitter unless given) -> (img, seg)."""
         with torch.no_grad():
             if graphed is not None:
-                img, seg = graphed(z, cond, cams)
-            else:
-                ws = G.mapping(z, cond)
-                img, seg = G.synthesis(ws, c=cams, noise_mode='const', return_seg=True)
+                return graphed(z, c_cond, c_cam, jitter=jitter)
+            ws = G.mapping(z.float(), c_cond)
+            return G.synthesis(ws, c=c_cam, noise_mode='const', return_seg=True, ray_jitter=jitter)
+
+    def step(i):
+        seeds = [(i * world + rank) * BATCH + j for j in range(BATCH)]
+        z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(spec.z_dim) for s in seeds])).to(device)
+        img, seg = render(z, cond, cams)
+        with torch.no_grad():
             frames = dr.frames_u8(img, seg, palette)
         if dist:
             dist.gather(frames, gathered, dst=0)
         return frames
 
+    def barrier():
+        if dist:
+            dist.barrier()
+        sync()
+
     for i in range(args.warmup):
         step(i)
+    block_s, rank_s = [], []
+    done = args.warmup
+    for _b in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(done + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        done += args.steps
+        mine = dt
+        if dist:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        block_s.append(dt); rank_s.append(mine)
+
+    # N > 1 extras: per-rank frame rates (own clock, median block) and the cost of the RCCL gather alone
+    per_rank, gather_ms = None, None
     if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        mine = torch.tensor([BATCH * args.steps / sorted(rank_s)[len(rank_s) // 2]], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t) for t in allr]
+        frames = step(done); done += 1
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.gather(frames, gathered, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - t0) / 5 * 1e3
 
     if rank == 0:
-        frames_total = BATCH * world * args.steps
+        order = sorted(block_s)
+        med = order[len(order) // 2]
+        frames_block = BATCH * world * args.steps
         out = {
-            'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': frames_total / dt, 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': frames_block / med, 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'gen_images.py-style: random-init ide3d-ffhq-64-512, G.mapping + G.synthesis (64 neural render -> 512, '
                                    '96 samples, RGB + 19-class seg) + uint8 frame conversion, batch = 4 seeds per GPU',
                        'global_batch': BATCH * world, 'parallelism': f'dp{world} (one rank per GPU, RCCL gather of uint8 frames)'},
-            'frames_per_s_per_gpu': frames_total / dt / world,
-            'conv_tflops': conv_flops(spec, BATCH) * args.steps / dt / 1e12,
-            'native_launches': dict(hip_plugin.CALLS), 'hip_graph': graphed is not None,
+            'timing': {'blocks': len(block_s), 'steps_per_block': args.steps, 'reported': 'median block',
+                       'ms_per_step_min': order[0] / args.steps * 1e3, 'ms_per_step_median': med / args.steps * 1e3,
+                       'ms_per_step_max': order[-1] / args.steps * 1e3, 'frames_per_s_min': frames_block / order[-1],
+                       'frames_per_s_max': frames_block / order[0]},
+            'frames_per_s_per_gpu': frames_block / med / world,
+            'conv_tflops': conv_flops(spec, BATCH) * args.steps / med / 1e12,
+            'native_launches': dict(hip_plugin.CALLS) if hip_plugin else {}, 'hip_graph': graphed is not None,
         }
-        if not args.no_roofline:
+        if dist:
+            out['rccl_ranks'] = world
+            out['frames_per_s_by_rank'] = per_rank
+            out['gather_ms'] = gather_ms
+            out['gather_bytes_per_rank_per_step'] = BATCH * res * 2 * res * 3
+        if cpu:
+            out['metric'] = 'DRY RUN (CPU tensors, tiny generator, gloo): launcher / protocol self-test, not a measurement'
+            out['data'] = 'synthetic (cpu dry run)'
+        pin = None
+        if not cpu and not args.no_parity:
+            out['parity'], got = check_parity(render, device)
+            out['parity_ok'] = out['parity'].get('ok')
+            pin = parity_inputs()
+        if not cpu and not args.no_roofline:
             out['roofline'] = bench_gather(device)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if not cpu and world == 1 and not args.no_roofline_extra:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+                import kernel_rooflines
+                out['roofline_extra'] = kernel_rooflines.measure_all(device, iters=10)
+            except Exception as e:
+                out['roofline_extra'] = {'error': f'{type(e).__name__}: {e}'}
+        if not cpu and world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'], live = cpu_baseline(parity_inputs=pin)
+            if live is not None and pin is not None:
+                img, seg = got
+                e_img = float((img[:1] - live['image']).abs().max()) / float(live['image'].abs().max())
+                e_seg = float((seg[:1] - live['image_seg']).abs().max()) / float(live['image_seg'].abs().max())
+                out['parity_live'] = {'what': 'image 0 of the parity step vs the oracle frame computed in the cpu_baseline leg of this run',
+                                      'max_rel_err': {'img': e_img, 'seg': e_seg}, 'tol_rel': 2e-3, 'ok': bool(max(e_img, e_seg) <= 2e-3)}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()

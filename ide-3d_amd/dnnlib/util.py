@@ -167,3 +167,58 @@ def layout_grid(img, grid_w=None, grid_h=1, float_to_uint8=True, chw_to_hwc=True
     if to_numpy:
         img = img.cpu().numpy()
     return img
+
+
+# ---- what the untouched driver scripts ask of `dnnlib.util` beyond the render path ---------------------------------------
+
+def open_url(url: str, cache_dir: str = None, num_attempts: int = 10, verbose: bool = True, return_filename: bool = False,
+             cache: bool = True) -> Any:
+    """Binary file object of a network pickle (reference util.py:402): local paths and file:// URLs.  Anything that needs the
+    network is handed to the reference's own `open_url` when its `dnnlib` sits behind this overlay on sys.path."""
+    import re
+    if not re.match('^[a-z]+://', url):
+        return url if return_filename else open(url, 'rb')
+    if url.startswith('file://'):
+        import urllib.parse
+        filename = urllib.parse.urlparse(url).path
+        if re.match(r'^/[a-zA-Z]:', filename):
+            filename = filename[1:]
+        return filename if return_filename else open(filename, 'rb')
+    ref = _reference_util()
+    if ref is None:
+        raise IOError(f'open_url: {url!r} needs the network; only local files and file:// URLs are handled by the overlay')
+    return ref.open_url(url, cache_dir=cache_dir, num_attempts=num_attempts, verbose=verbose, return_filename=return_filename, cache=cache)
+
+
+_ref_util = False
+
+
+def _reference_util():
+    """The reference's own dnnlib/util.py, when a reference checkout sits behind this overlay on sys.path (the overlay package
+    extends its __path__ over it), loaded under a private name; None otherwise."""
+    global _ref_util
+    if _ref_util is False:
+        _ref_util = None
+        import os
+        import importlib.util
+        import dnnlib
+        here = os.path.dirname(os.path.abspath(__file__))
+        for d in list(dnnlib.__path__):
+            cand = os.path.join(d, 'util.py')
+            if os.path.abspath(d) != here and os.path.isfile(cand):
+                spec = importlib.util.spec_from_file_location('dnnlib._reference_util', cand)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _ref_util = mod
+                break
+    return _ref_util
+
+
+def __getattr__(name: str) -> Any:
+    """Helpers this overlay does not re-state (Logger, format_time, make_cache_dir_path, ...) come from the reference's util."""
+    if name.startswith('__'):
+        raise AttributeError(name)
+    ref = _reference_util()
+    if ref is not None and hasattr(ref, name):
+        return getattr(ref, name)
+    raise AttributeError(f"module 'dnnlib.util' has no attribute {name!r}")

@@ -560,12 +560,26 @@ class VolumeRenderPlugin:
             t = mlp[k]
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), f'{k} must be contiguous float32 on GPU')
             setattr(p, k, t.data_ptr())
+            _require(t.device == tex_planes.device, f'{k} must reside on the same device as the tri-planes')
         n, c3, H, W = tex_planes.shape
         _require(geo_planes.shape == tex_planes.shape, 'texture and geometry tri-planes must have the same shape')
-        p.n, p.C, p.H, p.W = n, c3 // 3, H, W
-        p.hidden = mlp['geo_w0'].shape[0]
-        p.seg_ch = mlp['geo_w1'].shape[0] - 1
-        p.feat_ch = mlp['tex_w1'].shape[0]
+        _require(geo_planes.device == tex_planes.device, 'texture and geometry tri-planes must reside on the same device')
+        _require(c3 % 3 == 0, 'tri-planes must be [n, 3*C, H, W]')
+        C = c3 // 3
+        _require(mlp['geo_w0'].ndim == 2 and mlp['geo_w1'].ndim == 2 and mlp['tex_w0'].ndim == 2 and mlp['tex_w1'].ndim == 2,
+                 'decoder weights must be [out, in] matrices')
+        hidden = mlp['geo_w0'].shape[0]
+        nout_geo, nout_tex = mlp['geo_w1'].shape[0], mlp['tex_w1'].shape[0]
+        # the kernel indexes w0[row * C + col], b0[row], w1[row * hidden + col], b1[row] for the compiled (C, hidden): every
+        # tensor must have exactly that shape, and both branches the same hidden width
+        for k, shape in (('geo_w0', (hidden, C)), ('tex_w0', (hidden, C)), ('geo_b0', (hidden,)), ('tex_b0', (hidden,)),
+                         ('geo_w1', (nout_geo, hidden)), ('tex_w1', (nout_tex, hidden)), ('geo_b1', (nout_geo,)), ('tex_b1', (nout_tex,))):
+            _require(tuple(mlp[k].shape) == shape, f'{k} must be {list(shape)} (C={C}, hidden={hidden}), got {list(mlp[k].shape)}')
+        _require(nout_geo >= 1, 'geo_w1 must have at least the sigma row')
+        p.n, p.C, p.H, p.W = n, C, H, W
+        p.hidden = hidden
+        p.seg_ch = nout_geo - 1
+        p.feat_ch = nout_tex
 
     @staticmethod
     def render_rays(rays_d_cam, z_lin, cam2world, jitter, sigma_noise, tex_planes, geo_planes, mlp,
@@ -666,6 +680,7 @@ class ModconvPlugin:
         styles / dcoefs / noise / bias may be None."""
         for t in (x, w):
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'modconv2d: contiguous float32 CUDA tensors required')
+        _require(w.device == x.device, 'modconv2d: w must reside on the same device as x')
         n, cin, h, wd = x.shape
         per_image = (w.ndim == 5)             # [n, cout, cin, k, k]: styles already folded into per-image weights
         if per_image:
@@ -677,13 +692,19 @@ class ModconvPlugin:
         oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (((h - 3) // 2 + 1, (wd - 3) // 2 + 1) if mode == 1 else (h, wd))
         y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
         lib = load()
-        key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index)
+        # one workspace per (weight, problem shape, device, stream): the split-K partials inside it belong to one launch at a
+        # time, and launches on different streams (a graph replay next to an eager call) must not share them
+        key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index,
+               torch.cuda.current_stream(x.device).cuda_stream)
         ent = ModconvPlugin._ws.get(key)
         if ent is None:
             nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode, int(per_image))
             _require(nbytes >= 0, 'modconv2d: unsupported configuration')
-            if len(ModconvPlugin._ws) > 256:
-                ModconvPlugin._ws.clear()
+            if len(ModconvPlugin._ws) > 1024:
+                # drop only workspaces whose weight tensor is gone (nothing can launch with them again): a captured hipGraph
+                # holds raw pointers into the live ones, so those are never freed behind its back
+                for k_dead in [k_ for k_, e_ in ModconvPlugin._ws.items() if e_[2] is not None and e_[2]() is None]:
+                    del ModconvPlugin._ws[k_dead]
             ent = [torch.empty([max(nbytes // 4, 1)], dtype=torch.float32, device=x.device), None, None]
             ModconvPlugin._ws[key] = ent
         p = _ModconvParams()
@@ -693,6 +714,7 @@ class ModconvPlugin:
             if t is not None:
                 t = t.contiguous(); keep.append(t)
                 _require(t.is_cuda and t.dtype == torch.float32, f'modconv2d: {name} must be float32 on GPU')
+                _require(t.device == x.device, f'modconv2d: {name} must reside on the same device as x')
                 setattr(p, name, t.data_ptr())
         p.n, p.cin, p.cout, p.h, p.w_, p.k = n, cin, cout, h, wd, k
         p.noise_strength = float(noise_strength)
@@ -718,6 +740,8 @@ class StylePlugin:
         n, wdim = w.shape
         cin = affine_w.shape[0]
         _require(affine_w.is_contiguous() and affine_w.dtype == torch.float32 and affine_w.shape[1] == wdim, 'style_demod: bad affine weight')
+        for name, t in (('affine_w', affine_w), ('affine_b', affine_b), ('wsq_t', wsq_t)):
+            _require(t is None or t.device == w.device, f'style_demod: {name} must reside on the same device as w')
         styles = torch.empty([n, cin], dtype=torch.float32, device=w.device)
         dcoefs = None
         cout = 0
@@ -740,6 +764,7 @@ class StylePlugin:
         cout1 = w1.shape[0]
         for t in (a0, b0, w0, a1, b1, w1):
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'fold_heads: contiguous float32 CUDA tensors required')
+            _require(t.device == w.device, 'fold_heads: all tensors must reside on the same device as w')
         out = torch.empty([n, cout0 + cout1, cin, 1, 1], dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             rc = load().ide3d_fold_heads(_ptr(w), w.stride(0), n, cin, wdim, float(affine_gain), _ptr(a0), _ptr(b0), _ptr(w0), cout0, float(gain0),

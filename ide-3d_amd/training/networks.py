@@ -50,14 +50,27 @@ def _style_init():
     return True
 
 
+def _stamp(t):
+    """What has to be unchanged for a tensor derived from parameter `t` to be still valid: `Module.to(device)` and
+    `param.data = ...` keep the Parameter object and its `_version` but change the storage, so device and address count."""
+    return (t._version, t.device, t.data_ptr())
+
+
+def _evict_dead(cache, limit=512):
+    """Bound a derived-tensor cache by dropping entries whose source tensor is gone.  Live entries are never freed: a
+    captured hipGraph holds raw pointers into them (a blanket `.clear()` would leave its replays reading freed memory)."""
+    if len(cache) > limit:
+        for k in [k for k, e in cache.items() if e[0]() is None]:
+            del cache[k]
+
+
 def _wsq_t(weight):
-    """[Cin, Cout] = sum_k W[o, i, k]^2 transposed, cached per weight tensor and version (inference only).  An entry is
-    valid only for the tensor object it was computed from (ids and storage addresses get recycled) at the same `_version`."""
+    """[Cin, Cout] = sum_k W[o, i, k]^2 transposed, cached per weight tensor (inference only).  An entry is valid only for
+    the tensor object it was computed from (ids and storage addresses get recycled) at the same version / device / address."""
     ent = _wsq_cache.get(id(weight))
-    if ent is None or ent[0]() is not weight or ent[1] != weight._version:
-        if len(_wsq_cache) > 512:
-            _wsq_cache.clear()
-        ent = (weakref.ref(weight), weight._version, weight.detach().square().sum(dim=[2, 3]).t().contiguous())
+    if ent is None or ent[0]() is not weight or ent[1] != _stamp(weight):
+        _evict_dead(_wsq_cache)
+        ent = (weakref.ref(weight), _stamp(weight), weight.detach().square().sum(dim=[2, 3]).t().contiguous())
         _wsq_cache[id(weight)] = ent
     return ent[2]
 
@@ -66,8 +79,14 @@ def _wsq_t(weight):
 # The styles, demodulation coefficients and folded head weights of every layer depend only on `ws`, not on the
 # activations: `prefetch_styles` computes them up front on a side stream (43 small launches per synthesis pass that would
 # otherwise sit between the big convolution launches of the main stream) and the layers pick their result up by identity.
-_prefetched = {}          # id(affine module) -> (w data_ptr, result, event)
+import threading
+
+_tls = threading.local()  # .prefetched: {id(affine module) -> (w data_ptr, result, event)} of the synthesis pass running on this thread
 _side_streams = {}        # device -> stream (module level: generators are pickled / deep-copied, streams cannot be)
+
+
+def _prefetch_table():
+    return getattr(_tls, 'prefetched', None)
 
 
 def side_stream(device):
@@ -89,8 +108,10 @@ def _style_plan(block, ws_block):
 
 
 def prefetch_styles(blocks_and_ws, side_stream):
-    """Run the style kernels of all layers of `blocks_and_ws` = [(block, ws_block), ...] on `side_stream`."""
-    _prefetched.clear()
+    """Run the style kernels of all layers of `blocks_and_ws` = [(block, ws_block), ...] on `side_stream`.  The results
+    live in a table owned by this call (thread-local, replaced per pass): two generators rendering on different threads
+    never see each other's entries.  Always pair with `finish_prefetch` in a try / finally."""
+    _prefetched = _tls.prefetched = {}
     main = torch.cuda.current_stream()
     side_stream.wait_stream(main)
     with torch.cuda.stream(side_stream):
@@ -112,11 +133,11 @@ def prefetch_styles(blocks_and_ws, side_stream):
 def finish_prefetch(side_stream):
     """Join the side stream (required before a hipGraph capture ends) and drop what was not consumed."""
     torch.cuda.current_stream().wait_stream(side_stream)
-    _prefetched.clear()
+    _tls.prefetched = None
 
 
 def _take_prefetched(key_module, w):
-    ent = _prefetched.pop(id(key_module), None)
+    ent = _prefetch_table().pop(id(key_module), None)
     if ent is None or ent[0] != w.data_ptr():
         return None
     main = torch.cuda.current_stream()
@@ -130,7 +151,7 @@ def _take_prefetched(key_module, w):
 def _styles_and_dcoefs(affine, w, weight, demodulate):
     """(styles, dcoefs) of a modulated conv: ONE HIP launch (csrc/style.hip) in inference on device tensors,
     otherwise the PyTorch definition."""
-    if _prefetched:
+    if _prefetch_table():
         hit = _take_prefetched(affine, w)
         if hit is not None:
             return hit
@@ -183,10 +204,9 @@ def _cat_cached(a, b):
     if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
         return torch.cat([a, b])
     ent = _cat_cache.get(id(a))
-    if ent is None or ent[0]() is not a or ent[1]() is not b or ent[2] != (a._version, b._version):
-        if len(_cat_cache) > 512:
-            _cat_cache.clear()
-        ent = (weakref.ref(a), weakref.ref(b), (a._version, b._version), torch.cat([a.detach(), b.detach()]))
+    if ent is None or ent[0]() is not a or ent[1]() is not b or ent[2] != (_stamp(a), _stamp(b)):
+        _evict_dead(_cat_cache)
+        ent = (weakref.ref(a), weakref.ref(b), (_stamp(a), _stamp(b)), torch.cat([a.detach(), b.detach()]))
         _cat_cache[id(a)] = ent
     return ent[3]
 
@@ -195,10 +215,9 @@ def _scaled_weight(weight, gain):
     """weight * gain (the equalised-learning-rate factor), formed once per (tensor object, version) in inference so that
     the packed copy inside the HIP workspace stays valid across calls."""
     ent = _wscale_cache.get(id(weight))
-    if ent is None or ent[0]() is not weight or ent[1] != (weight._version, float(gain)):
-        if len(_wscale_cache) > 512:
-            _wscale_cache.clear()
-        ent = (weakref.ref(weight), (weight._version, float(gain)), (weight.detach() * gain).contiguous())
+    if ent is None or ent[0]() is not weight or ent[1] != (_stamp(weight), float(gain)):
+        _evict_dead(_wscale_cache)
+        ent = (weakref.ref(weight), (_stamp(weight), float(gain)), (weight.detach() * gain).contiguous())
         _wscale_cache[id(weight)] = ent
     return ent[2]
 
@@ -210,10 +229,9 @@ def _scaled_const_noise(noise_const, noise_strength):
         return noise_const * noise_strength
     ent = _noise_cache.get(id(noise_const))
     if (ent is None or ent[0]() is not noise_const or ent[1]() is not noise_strength
-            or ent[2] != (noise_const._version, noise_strength._version, noise_const.device)):
-        if len(_noise_cache) > 512:
-            _noise_cache.clear()
-        ent = (weakref.ref(noise_const), weakref.ref(noise_strength), (noise_const._version, noise_strength._version, noise_const.device),
+            or ent[2] != (_stamp(noise_const), _stamp(noise_strength))):
+        _evict_dead(_noise_cache)
+        ent = (weakref.ref(noise_const), weakref.ref(noise_strength), (_stamp(noise_const), _stamp(noise_strength)),
                (noise_const * noise_strength).detach())
         _noise_cache[id(noise_const)] = ent
     return ent[3]
@@ -329,7 +347,7 @@ def _dual_head(x, torgb, toseg, w):
     n = x.shape[0]
     if w.shape[0] != n:
         return None
-    wcat = _take_prefetched(torgb, w) if _prefetched else None
+    wcat = _take_prefetched(torgb, w) if _prefetch_table() else None
     if wcat is None:
         wcat = _folded_head_weights(torgb, toseg, w)
     if wcat is None:

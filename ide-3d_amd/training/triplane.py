@@ -333,25 +333,28 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         # than the overlap returns (measured: -11 % on the eager video driver, +2.4 % on the graphed renderer)
         prefetch = (getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled()
                     and torch.cuda.is_current_stream_capturing() and not os.environ.get('IDE3D_NO_STYLE_PREFETCH'))
-        if prefetch:
-            # all style / demodulation / head-folding launches of this pass go to a side stream (they depend only on ws)
-            side = networks.side_stream(ws.device)
-            todo = [] if cached_planes is not None else [(getattr(self, f'vb{r}'), w) for r, w in zip(self.voxel_block_resolutions, voxel_ws)]
-            todo += [(getattr(self, f'b{r}'), w) for r, w in zip(self.block_resolutions, block_ws)]
-            networks.prefetch_styles(todo, side)
-        if cached_planes is not None:
-            img_v, seg_v = cached_planes
-        else:
-            img_v, seg_v = self.backbone(voxel_ws, **block_kwargs)
-        cam2world = c[:, :16].reshape(-1, 4, 4).to(torch.float32)
-        feat, depth, wsum = self.renderer(
-            img_v, seg_v, cam2world, fov=render_params.get('fov'), num_steps=render_params.get('num_steps'),
-            ray_start=render_params.get('ray_start'), ray_end=render_params.get('ray_end'),
-            nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter,
-            hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
-        img, seg = self.superres(feat, block_ws, **block_kwargs)
-        if prefetch:
-            networks.finish_prefetch(side)
+        side = None
+        try:
+            if prefetch:
+                # all style / demodulation / head-folding launches of this pass go to a side stream (they depend only on ws)
+                side = networks.side_stream(ws.device)
+                todo = [] if cached_planes is not None else [(getattr(self, f'vb{r}'), w) for r, w in zip(self.voxel_block_resolutions, voxel_ws)]
+                todo += [(getattr(self, f'b{r}'), w) for r, w in zip(self.block_resolutions, block_ws)]
+                networks.prefetch_styles(todo, side)
+            if cached_planes is not None:
+                img_v, seg_v = cached_planes
+            else:
+                img_v, seg_v = self.backbone(voxel_ws, **block_kwargs)
+            cam2world = c[:, :16].reshape(-1, 4, 4).to(torch.float32)
+            feat, depth, wsum = self.renderer(
+                img_v, seg_v, cam2world, fov=render_params.get('fov'), num_steps=render_params.get('num_steps'),
+                ray_start=render_params.get('ray_start'), ray_end=render_params.get('ray_end'),
+                nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter,
+                hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
+            img, seg = self.superres(feat, block_ws, **block_kwargs)
+        finally:
+            if side is not None:
+                networks.finish_prefetch(side)      # joins the side stream and drops the table even when a layer raised
         img_raw = feat[:, :self.img_channels]
         if return_dict:
             return dict(image=img, image_seg=seg, image_raw=img_raw, image_depth=depth, planes=(img_v, seg_v))
@@ -413,14 +416,27 @@ class GraphedRenderer:
 
         run = GraphedRenderer(G, batch=4, device=dev)          # warms up, then captures
         img, seg = run(z, c_cond, c_cam)                       # z [B, z_dim] float64/32, labels [B, 25]
+        img, seg = run(z, c_cond, c_cam, jitter=u)             # u [B, R*R, S]: the stratified-jitter draws of this call
+
+    Stratified jitter (the reference draws it on every call, volumetric_rendering.py:113): the captured pass reads a static
+    buffer `self.jitter`; a call refills it with fresh U[0,1) draws on the device, or with the caller's draws (parity
+    tests, `bench.py`'s parity check).  `ray_jitter=False` captures the pass without jitter.
     """
 
     def __init__(self, G, batch, device, truncation_psi=1.0, noise_mode='const', warmup=3, ray_jitter=None):
         self.G = G
-        self.psi, self.noise_mode, self.ray_jitter = truncation_psi, noise_mode, ray_jitter
+        self.psi, self.noise_mode = truncation_psi, noise_mode
         self.z = torch.zeros([batch, G.z_dim], dtype=torch.float32, device=device)
         self.c_cond = conditioning_label(device).repeat(batch, 1)
         self.c_cam = conditioning_label(device).repeat(batch, 1)
+        sp = G.synthesis.spec
+        if ray_jitter is False:
+            self.jitter = None
+        else:
+            self.jitter = torch.rand([batch, sp.render_size ** 2, sp.num_steps], device=device)
+            if ray_jitter is not None:
+                self.jitter.copy_(ray_jitter)
+        self._fixed_jitter = ray_jitter is not None and ray_jitter is not False
         self.graph = None
         stream = torch.cuda.Stream(device=device)
         stream.wait_stream(torch.cuda.current_stream(device))
@@ -429,20 +445,29 @@ class GraphedRenderer:
                 self._body()
         torch.cuda.current_stream(device).wait_stream(stream)
         torch.cuda.synchronize(device)
+        # capture on the warm-up stream: per-layer workspaces (packed weights) are keyed by stream, so the replays reuse the
+        # copies packed during warm-up instead of re-packing inside the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        with torch.no_grad(), torch.cuda.graph(graph, stream=stream):
             self.out = self._body()
         self.graph = graph
+        self._stream = stream
 
     def _body(self):
         ws = self.G.mapping(self.z, self.c_cond, truncation_psi=self.psi)
-        return self.G.synthesis(ws, c=self.c_cam, noise_mode=self.noise_mode, return_seg=True, ray_jitter=self.ray_jitter)
+        return self.G.synthesis(ws, c=self.c_cam, noise_mode=self.noise_mode, return_seg=True,
+                                ray_jitter=(False if self.jitter is None else self.jitter))
 
-    def __call__(self, z, c_cond=None, c_cam=None):
+    def __call__(self, z, c_cond=None, c_cam=None, jitter=None):
         self.z.copy_(z)
         if c_cond is not None:
             self.c_cond.copy_(c_cond)
         if c_cam is not None:
             self.c_cam.copy_(c_cam)
+        if self.jitter is not None:
+            if jitter is not None:
+                self.jitter.copy_(jitter)
+            elif not self._fixed_jitter:
+                self.jitter.uniform_()
         self.graph.replay()
         return self.out

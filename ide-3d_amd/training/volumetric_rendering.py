@@ -290,8 +290,7 @@ def _fused_ray_setup(device, fov, resolution, num_steps, ray_start, ray_end):
     key = (str(device), fov, resolution, num_steps, ray_start, ray_end)
     ent = _ray_setup_cache.get(key)
     if ent is None:
-        if len(_ray_setup_cache) > 64:
-            _ray_setup_cache.clear()
+        # entries are tiny ([R, 3] + [S]) and a captured hipGraph may hold their pointers: never freed
         ent = (_camera_rays(device, fov, resolution).contiguous(), torch.linspace(ray_start, ray_end, num_steps, device=device))
         _ray_setup_cache[key] = ent
     return ent
@@ -307,8 +306,9 @@ def render_triplane_fused(tex_planes, geo_planes, mlp, cam2world, fov, resolutio
          runtime gains folded in).
     cam2world: [N, 4, 4].  jitter: U[0,1) draws [N, R, S] (None = no stratified jitter).
     sigma_noise: [N, R, S] density noise already scaled by noise_std, or None.
-    Returns (features [N, feat+seg, H_r, W_r], depth [N, 1, H_r, W_r], weight_sum [N, 1, H_r, W_r]).
-    Raises RuntimeError if the fused kernel does not support the configuration.
+    Returns (features [N, feat+seg, H_r, W_r], depth [N, 1, H_r, W_r], weight_sum [N, 1, H_r, W_r]), or None when the
+    library has no fused kernel for the configuration (IDE3D_ENOKERNEL: plane_channels / decoder widths other than
+    the compiled (32, 64) and (16, 32)) — the caller then runs the step-wise HIP ops.  Launch failures raise RuntimeError.
     """
     assert clamp_mode in ('softplus', 'relu')
     _init()
@@ -319,7 +319,10 @@ def render_triplane_fused(tex_planes, geo_planes, mlp, cam2world, fov, resolutio
         tex_planes = tex_planes.contiguous(memory_format=torch.channels_last)
     if geo_planes.stride(1) != 1:
         geo_planes = geo_planes.contiguous(memory_format=torch.channels_last)
-    feat, depth, wsum = _plugin.render_rays(rays_d_cam, z_lin, cam2world, jitter, sigma_noise, tex_planes, geo_planes, mlp,
-                                            0 if clamp_mode == 'softplus' else 1, False, white_back, max_depth)
+    res = _plugin.render_rays(rays_d_cam, z_lin, cam2world, jitter, sigma_noise, tex_planes, geo_planes, mlp,
+                              0 if clamp_mode == 'softplus' else 1, False, white_back, max_depth)
+    if res is None:
+        return None
+    feat, depth, wsum = res
     n = tex_planes.shape[0]
     return feat.reshape(n, -1, H, W), depth.reshape(n, 1, H, W), wsum.reshape(n, 1, H, W)

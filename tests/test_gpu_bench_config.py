@@ -1,0 +1,203 @@
+"""Parity at the configurations that are BENCHMARKED (BASELINE.json configs 2, 3 and 5), not at reduced sizes:
+
+  config 2  full-size ide3d-ffhq-64-512, batch 4, hipGraph replay (`GraphedRenderer`, side-stream style prefetch, image-batched
+            tiles) — exactly what `bench.py` times: all four images vs the CPU oracle, and graph == eager bit for bit;
+  config 3  one full-size 2x2 `image_seg` grid frame of `training.video_render` (cached tri-planes, uint8 colour mapping and
+            layout on the device) vs frames built from the oracle;
+  config 5  the 256^3 `extract_shapes.py` lattice: device lattice bit-equal to `create_samples(256)` (the float-division quirk
+            is exact at 256 only because 256^3 = 2^24 — this is the case that has to be run), sigma of the single-launch cube
+            vs the oracle on a strided subset;
+  plus the fall-back of the renderer for decoder shapes the fused kernel is not compiled for.
+
+Tolerances (fp32 everywhere): tri-planes 1e-3, raw / final images and seg logits 2e-3 of the tensor's scale (hundreds of fp32
+convolutions with a different summation order); uint8 frames within 1 LSB except < 0.5 % of pixels, seg argmax flips < 0.5 %.
+`pytest -m gpu`.
+"""
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fast_ops
+from oracle import generator as ogen
+from oracle import ops as oracle_ops
+from oracle import spec as ospec
+
+pytestmark = pytest.mark.gpu
+
+BENCH_YAWS = (-0.5, 0.0, 0.5, 0.25)          # bench.py's camera labels
+
+
+def _calls(name):
+    from torch_utils import hip_plugin
+    return hip_plugin.CALLS.get(name, 0)
+
+
+def _rel(actual, expected, tol, what):
+    a = actual.detach().cpu().double(); e = torch.as_tensor(expected).detach().cpu().double()
+    assert a.shape == e.shape, f'{what}: shape {tuple(a.shape)} != {tuple(e.shape)}'
+    scale = float(e.abs().max()) + 1e-12
+    err = float((a - e).abs().max())
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol} * scale {scale:.3e}'
+
+
+@pytest.fixture(scope='module')
+def oracle_threads():
+    """The fp32 torch-CPU oracle is fastest with a few dozen threads, not with one per core of a 256-thread host."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    yield
+    torch.set_num_threads(old)
+
+
+@pytest.fixture(scope='module')
+def bench_generator(gpu_device):
+    """The generator bench.py builds: torch.manual_seed(0) random init of the full-size spec (+ its CPU state dict)."""
+    from training import triplane
+    torch.manual_seed(0)
+    G = triplane.TriPlaneGenerator().eval()
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    return G.to(gpu_device), sd
+
+
+def test_config2_batch4_graph_replay_vs_oracle(bench_generator, gpu_device, oracle_threads):
+    from training import triplane
+    from training import distributed_render as dr
+    G, sd = bench_generator
+    B = 4
+    z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in range(B)]))
+    cams = torch.cat([triplane.camera_label(y) for y in BENCH_YAWS])
+    cond = triplane.conditioning_label().repeat(B, 1)
+    jit = torch.rand(B, 4096, 96, generator=torch.Generator().manual_seed(11))
+
+    run = triplane.GraphedRenderer(G, B, gpu_device)
+    # a replay with other inputs first: the compared replay must not depend on what the capture / previous call left behind
+    run(torch.randn(B, 512, device=gpu_device), cond.to(gpu_device), cams.flip(0).to(gpu_device))
+    img_g, seg_g = run(z.to(gpu_device), cond.to(gpu_device), cams.to(gpu_device), jitter=jit.to(gpu_device))
+    img_g, seg_g = img_g.clone(), seg_g.clone()
+    assert img_g.shape == (B, 3, 512, 512) and seg_g.shape == (B, 19, 512, 512)
+
+    before = _calls('render_rays')
+    with torch.no_grad():
+        ws = G.mapping(z.to(gpu_device).float(), cond.to(gpu_device))
+        out = G.synthesis(ws, c=cams.to(gpu_device), noise_mode='const', ray_jitter=jit.to(gpu_device), return_dict=True)
+    assert _calls('render_rays') == before + 1, 'the fused HIP ray-marcher must have run'
+    assert torch.equal(img_g, out['image']) and torch.equal(seg_g, out['image_seg']), 'hipGraph replay != eager launches at full size'
+
+    osp = ospec.Spec()
+    frames_gpu = dr.frames_u8(img_g, seg_g, dr.palette_tensor(19, gpu_device)).cpu().numpy()
+    for i in range(B):          # one oracle image at a time (memory)
+        ws_o = ogen.mapping(sd, osp, z[i:i + 1], cond[i:i + 1], ops=fast_ops)
+        _rel(ws[i:i + 1], ws_o, 1e-4, f'ws[{i}]')
+        ref = ogen.synthesis(sd, osp, ws_o, cams[i:i + 1], jitter=jit[i:i + 1], ops=fast_ops)
+        _rel(out['planes'][0][i:i + 1], ref['planes'][0], 1e-3, f'texture tri-plane [{i}]')
+        _rel(out['planes'][1][i:i + 1], ref['planes'][1], 1e-3, f'semantic tri-plane [{i}]')
+        _rel(out['image_raw'][i:i + 1], ref['image_raw'], 2e-3, f'raw 64x64 image [{i}]')
+        _rel(img_g[i:i + 1], ref['image'], 2e-3, f'image 512 [{i}]')
+        _rel(seg_g[i:i + 1], ref['image_seg'], 2e-3, f'seg 512 [{i}]')
+        want = oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0]
+        got = frames_gpu[i]
+        rgb_off = np.abs(got[:, :512].astype(np.int32) - want[:, :512].astype(np.int32)) > 1
+        assert rgb_off.mean() < 5e-3, f'uint8 RGB frame [{i}]: {rgb_off.mean():.4f} of the values differ by more than 1 LSB'
+        flips = (got[:, 512:] != want[:, 512:]).any(axis=-1)
+        assert flips.mean() < 5e-3, f'seg colour frame [{i}]: {flips.mean():.4f} argmax flips'
+
+
+def test_config3_full_size_grid_frame_vs_oracle(bench_generator, gpu_device, oracle_threads):
+    """gen_videos.py 2x2 grid, `image_seg`: frames 0 and 30 of a 120-frame sweep from `video_render` vs oracle-built frames."""
+    from training import video_render
+    G, sd = bench_generator
+    seeds, total, psi, cutoff = [0, 1, 2, 3], 120, 0.7, 14
+    want_idx = (0, 30)
+    before = _calls('frame_u8')
+    frames = {}
+    for i, f in enumerate(video_render.gen_interp_frames(G, seeds, w_frames=total, grid_dims=(2, 2), psi=psi, truncation_cutoff=cutoff,
+                                                         device=gpu_device, ray_jitter=False)):
+        if i in want_idx:
+            frames[i] = f.cpu().numpy()
+        if i >= max(want_idx):
+            break
+    assert _calls('frame_u8') > before
+    osp = ospec.Spec()
+    lookat = torch.tensor([0, 0, 0.2])
+    # frontal conditioning label of gen_videos.py:83-88 (host-side camera math, golden-pinned in tests/test_host_cpu.py)
+    front = video_render.LookAtPoseSampler.sample(math.pi / 2, math.pi / 2, lookat, radius=2.7)
+    c_front = torch.cat([front.reshape(1, 16), torch.tensor(video_render.INTRINSICS, dtype=torch.float32).reshape(1, 9)], 1)
+    zs = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in seeds]))
+    for idx in want_idx:
+        c = video_render.sweep_pose(idx, total, lookat)
+        cells = []
+        for k in range(4):
+            ws_o = ogen.mapping(sd, osp, zs[k:k + 1], c_front, truncation_psi=psi, truncation_cutoff=cutoff, ops=fast_ops)
+            ref = ogen.synthesis(sd, osp, ws_o, c, jitter=None, ops=fast_ops)
+            cells.append(oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0])
+        want = np.stack(cells).reshape(2, 2, 512, 1024, 3).transpose(0, 2, 1, 3, 4).reshape(1024, 2048, 3)
+        got = frames[idx]
+        assert got.shape == want.shape == (1024, 2048, 3)
+        is_seg = (np.arange(2048) % 1024) >= 512
+        rgb_off = np.abs(got[:, ~is_seg].astype(np.int32) - want[:, ~is_seg].astype(np.int32)) > 1
+        assert rgb_off.mean() < 5e-3, f'frame {idx}: {rgb_off.mean():.4f} of the RGB values differ by more than 1 LSB'
+        flips = (got[:, is_seg] != want[:, is_seg]).any(axis=-1)
+        assert flips.mean() < 5e-3, f'frame {idx}: {flips.mean():.4f} seg argmax flips'
+
+
+def test_config5_lattice_256_and_density_vs_oracle(bench_generator, gpu_device, oracle_threads):
+    """extract_shapes.py at voxel_resolution 256: the lattice, bit for bit, and the single-launch sigma cube."""
+    from training import shape_extraction as se
+    from training import triplane
+    G, sd = bench_generator
+    N = 256
+    dev, origin, vsize = se.create_samples(N, (0, 0, 0), 2.0, device=gpu_device)
+    want = oracle_ops.create_samples(N, (0, 0, 0), 2.0)
+    assert dev.shape == want.shape == (1, N ** 3, 3)
+    assert torch.equal(dev.cpu(), want), 'device lattice != extract_shapes.create_samples(256)'
+    del dev
+    z = torch.from_numpy(np.random.RandomState(0).randn(1, 512))
+    cond = triplane.conditioning_label()
+    osp = ospec.Spec()
+    ws_o = ogen.mapping(sd, osp, z, cond, truncation_psi=0.5, ops=fast_ops)
+    planes_o = ogen.backbone(sd, osp, ws_o, 'const', fast_ops)
+    before = _calls('density_lattice')
+    cube = se.sample_generator_ide3d(G, None, z.to(gpu_device), cond.to(gpu_device), max_batch=None, voxel_resolution=N,
+                                     cube_length=2.0, psi=0.5, to_numpy=False, noise_mode='const')
+    assert _calls('density_lattice') == before + 1, 'one launch for the whole cube'
+    assert cube.shape == (N, N, N)
+    chunked = se.sample_generator_ide3d(G, None, z.to(gpu_device), cond.to(gpu_device), max_batch=1000000, voxel_resolution=N,
+                                        cube_length=2.0, psi=0.5, to_numpy=False, noise_mode='const')
+    assert torch.equal(cube, chunked), 'chunked query loop != single launch'
+    sub = torch.arange(0, N ** 3, 4099)
+    pts = 0.9 * want[:, sub]
+    ref = ogen.sample_voxel(sd, osp, planes_o[0], planes_o[1], pts, fast_ops)[:, -1]
+    _rel(cube.reshape(-1)[sub.to(gpu_device)], ref, 1e-3, 'sigma at 256^3 (strided subset)')
+
+
+def test_renderer_falls_back_for_uncompiled_decoder_width(gpu_device):
+    """decoder_hidden = 48 has no fused kernel (IDE3D_ENOKERNEL): the renderer must take the step-wise HIP ops, not crash."""
+    from training import triplane
+    from training import volumetric_rendering as vr
+    torch.manual_seed(3)
+    sp = triplane.tiny_spec(decoder_hidden=48)
+    R = triplane.TriplaneRenderer(sp).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(4)
+    tex = torch.randn(2, 48, 32, 32, generator=g).to(gpu_device); geo = torch.randn(2, 48, 32, 32, generator=g).to(gpu_device)
+    cam = torch.cat([triplane.camera_label(0.3), triplane.camera_label(-0.2)])[:, :16].reshape(-1, 4, 4).to(gpu_device)
+    jit = torch.rand(2, 64, 12, generator=g).to(gpu_device)
+    vr._init()
+    assert vr.render_triplane_fused(tex.contiguous(memory_format=torch.channels_last), geo.contiguous(memory_format=torch.channels_last),
+                                    R.decoder.kernel_weights(), cam, sp.fov, (8, 8), 12, sp.ray_start, sp.ray_end, jitter=jit) is None
+    b_rr, b_c, b_g = _calls('render_rays'), _calls('composite'), _calls('triplane_sample_rays') + _calls('triplane_sample')
+    with torch.no_grad():
+        feat, depth, wsum = R(tex, geo, cam, jitter=jit)
+    assert _calls('render_rays') == b_rr and _calls('composite') == b_c + 1
+    assert _calls('triplane_sample_rays') + _calls('triplane_sample') == b_g + 2
+    sd = {'synthesis.renderer.' + k: v.detach().cpu() for k, v in R.state_dict().items()}
+    want = ogen.render(sd, ospec.tiny(decoder_hidden=48), tex.cpu(), geo.cpu(), cam.cpu(), jitter=jit.cpu(), ops=fast_ops)
+    _rel(feat, want[0], 3e-4, 'step-wise features'); _rel(depth, want[1], 1e-4, 'step-wise depth'); _rel(wsum, want[2], 1e-4, 'weight sum')
+    # mismatched decoder tensors are rejected before any launch (hip_plugin._fill_render_params)
+    bad = dict(R.decoder.kernel_weights()); bad['tex_w0'] = bad['tex_w0'][:32].contiguous()
+    with pytest.raises(RuntimeError, match='tex_w0'):
+        vr._plugin.sample_voxel(tex.contiguous(memory_format=torch.channels_last), geo.contiguous(memory_format=torch.channels_last),
+                                bad, torch.zeros(2, 4, 3, device=gpu_device))

@@ -198,6 +198,72 @@ def test_filtered_lrelu_signs_and_backward(gpu_device):
     assert_close(grads[0][1], grads[1][1], rtol=1e-4, atol=1e-3, what='db')
 
 
+def test_filtered_lrelu_sign_bytes_exact(gpu_device):
+    """The packed sign tensor is BYTE output: bit-exact, not "within tolerance".  Inputs are built so that every intermediate is
+    exactly representable (dyadic data, bias, filter taps, gain, slope and clamp: every fp32 product and partial sum is exact in
+    any order), hence the up-sampled value that is classified is bit-identical on the device and in the fp64 oracle, including
+    exact zeros and values exactly at the clamp.  Format: 4 x 2-bit codes per byte, element 4k + j in bits 2j..2j+1, code bit 0 =
+    negative, bit 1 = clamped (filtered_lrelu.cu:494-519); rows padded to a multiple of 16 elements (filtered_lrelu.cpp:89-93)."""
+    from torch_utils import hip_plugin
+    from torch_utils.ops import upfirdn2d
+    plug = hip_plugin.FilteredLReluPlugin
+    g = torch.Generator().manual_seed(16)
+    cases = (
+        # 2-D 4x4 filter [1,3,3,1] (x) [1,3,3,1] / 64, up 2 / down 2
+        (upfirdn2d.setup_filter([1, 3, 3, 1]), (2, 3, 13, 10), dict(up=2, down=2, padding=[2, 1, 2, 1], gain=2.0, slope=0.25, clamp=0.75)),
+        # separable 12-tap filter whose taps sum to 64, up 2 / down 2 (StyleGAN3 layer shape)
+        (upfirdn2d.setup_filter([1, 1, 2, 4, 8, 16, 16, 8, 4, 2, 1, 1], separable=True), (2, 4, 17, 19),
+         dict(up=2, down=2, padding=[10, 11, 10, 11], gain=2.0, slope=0.125, clamp=0.5)),
+        # up 4 / down 2, no clamp
+        (upfirdn2d.setup_filter([1, 1, 2, 4, 8, 16, 16, 8, 4, 2, 1, 1], separable=True), (1, 2, 9, 12),
+         dict(up=4, down=2, padding=[10, 11, 10, 11], gain=4.0, slope=0.5, clamp=None)),
+    )
+    for f, shape, kw in cases:
+        x = torch.randint(-6, 7, shape, generator=g).float() / 4
+        b = torch.randint(-4, 5, (shape[1],), generator=g).float() / 8
+        p = kw['padding']
+        clamp = kw['clamp'] if kw['clamp'] is not None else float('inf')
+        y, so, rc = plug.filtered_lrelu(x.to(gpu_device), f.to(gpu_device), f.to(gpu_device), b.to(gpu_device), torch.empty([0]),
+                                        kw['up'], kw['down'], p[0], p[1], p[2], p[3], 0, 0, kw['gain'], kw['slope'], clamp, False, True)
+        assert rc == 0
+        yo, codes = oracle_ops.filtered_lrelu(x, fu=f, fd=f, b=b, return_signs=True, **kw)
+        codes = codes.numpy()
+        frac = [float((codes == k).mean()) for k in range(3)]
+        assert frac[0] > 0.05 and frac[1] > 0.05 and (kw['clamp'] is None or frac[2] > 0.05), f'degenerate test data: code frequencies {frac}'
+        # the classified (up-sampled) values need <= 18 mantissa bits in every case; the final output only for the 4x4 filter (the
+        # two 1-D down-sampling passes of the separable filter add 12 more bits), so only there it must be bit-equal as well
+        if f.ndim == 2:
+            assert torch.equal(y.cpu(), yo.float()), 'exactly representable data: the output itself must be bit-equal too'
+        else:
+            assert_close(y, yo, rtol=1e-5, atol=1e-5, what='y')
+        so = so.cpu().numpy()
+        n, c, H, Wc = codes.shape
+        assert so.dtype == np.uint8 and so.shape[:2] == (n, c) and so.shape[2] >= H and so.shape[3] * 4 >= Wc and (so.shape[3] * 4) % 16 == 0
+        full = Wc // 4
+        packed = np.zeros((n, c, H, (Wc + 3) // 4), dtype=np.uint8)
+        for j in range(4):
+            col = codes[:, :, :, j::4].astype(np.uint8) << (2 * j)
+            packed[:, :, :, :col.shape[3]] |= col
+        assert np.array_equal(so[:, :, :H, :full], packed[:, :, :, :full]), f'packed sign bytes differ: {kw}'
+        if Wc % 4:                          # last, partially valid byte of a row: compare the valid 2-bit fields only
+            mask = np.uint8((1 << (2 * (Wc % 4))) - 1)
+            assert np.array_equal(so[:, :, :H, full] & mask, packed[:, :, :, full] & mask)
+        # reading the signs back (backward-pass mode of the same kernel) reproduces gain * slope / 0 / gain per element
+        dy = torch.randint(-4, 5, x.shape, generator=g).float() / 4
+        dx, _so2, rc = plug.filtered_lrelu(dy.to(gpu_device), f.to(gpu_device), f.to(gpu_device), torch.zeros(shape[1], device=gpu_device),
+                                           plug.filtered_lrelu(x.to(gpu_device), f.to(gpu_device), f.to(gpu_device), b.to(gpu_device), torch.empty([0]),
+                                                               kw['up'], kw['down'], p[0], p[1], p[2], p[3], 0, 0, kw['gain'], kw['slope'], clamp, False, True)[1],
+                                           kw['up'], kw['down'], p[0], p[1], p[2], p[3], 0, 0, kw['gain'], kw['slope'], clamp, False, False)
+        assert rc == 0
+        z = oracle_ops.upfirdn2d(dy.double(), f, up=kw['up'], padding=p, gain=kw['up'] ** 2).numpy()
+        scale = np.where(codes == 2, 0.0, np.where(codes == 1, kw['gain'] * kw['slope'], kw['gain']))
+        want = oracle_ops.upfirdn2d(torch.from_numpy(z * scale), f, down=kw['down']).float()
+        if f.ndim == 2:
+            assert torch.equal(dx.cpu(), want), 'sign-read mode'
+        else:
+            assert_close(dx, want, rtol=1e-5, atol=1e-5, what='sign-read mode')
+
+
 def test_filtered_lrelu_generic_fallback_path(gpu_device):
     """`return_code = -1` route: upfirdn2d -> filtered_lrelu_act_ -> upfirdn2d (float64 has no fused kernel)."""
     from torch_utils.ops import filtered_lrelu, upfirdn2d
