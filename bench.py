@@ -104,8 +104,12 @@ def conv_flops(spec, n_images):
     return fl * n_images
 
 
-def bench_gather(device, iters=20, tiled=True):
-    """Isolated `sample_from_triplane` at the benchmark shape (N=4 images, channels_last planes): HIP events.
+def bench_gather(device, iters=100, tiled=True, warm_launches=400):
+    """Isolated `sample_from_triplane` at the benchmark shape (N=4 images, channels_last planes): HIP events around each of
+    `iters` launches, after `warm_launches` untimed ones.  The warm-up matters: the GPU's power management needs ~30 ms of
+    continuous load to reach its sustained clocks (measured with scripts/micro/gather_bench: the same kernel takes 92 us in
+    its first 30 launches after an idle period and 76.5 us from launch ~300 on) — inside the render pipeline the GPU is
+    busy back to back, so the sustained figure is the representative one.
     tiled=True passes the ray-grid hint the renderer has (LDS-staged kernel); False times the flat kernel."""
     from dnnlib import util
     g = torch.Generator().manual_seed(0)
@@ -120,9 +124,8 @@ def bench_gather(device, iters=20, tiled=True):
     coords = (wp.reshape(n, M, 3) * float(os.environ.get('IDE3D_BENCH_COORD_SCALE', '1'))).contiguous()   # experiment knob
     del pts, z, d, wp
     ray_grid = (64, 64, 96) if tiled else None
-    for _ in range(3):
+    for _ in range(max(3, warm_launches)):
         util.sample_from_triplane(coords, planes, ray_grid=ray_grid)
-    torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in evs:
         a.record(); util.sample_from_triplane(coords, planes, ray_grid=ray_grid); b.record()
@@ -141,7 +144,8 @@ def bench_gather(device, iters=20, tiled=True):
     rate = algo / (avg * 1e-3)
     return dict(kernel='triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel', bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9,
                 unit='GB/s', frac=rate / HBM_PEAK, frac_of_measured_copy_ceiling=rate / HBM_COPY, traffic=traffic, bytes_per_launch=algo,
-                avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3,
+                avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3, median_launch_us=ms[len(ms) // 2] * 1e3,
+                timed_launches=iters, warm_launches=warm_launches,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 
 

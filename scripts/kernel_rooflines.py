@@ -15,6 +15,7 @@ import json
 import math
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (os.path.join(ROOT, 'ide-3d_amd'), ROOT):
@@ -49,8 +50,13 @@ def _time(fn, iters, device, eager=False):
             with torch.cuda.graph(graph, stream=stream):
                 for _ in range(iters):
                     fn()
+            # warm-up to sustained clocks: ~30 ms of continuous load (power management), then one timed replay
             graph.replay()
             stream.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.04:
+                graph.replay()
+                stream.synchronize()
             e0.record(stream)
             graph.replay()
             e1.record(stream)
