@@ -1,0 +1,196 @@
+// mapping.hip — the whole mapping network z, c -> ws in ONE launch.
+//
+// Replaces `MappingNetwork.forward` (inversion/networks.py:287-325) in inference:
+//   x = normalize_2nd_moment(z)                                   networks.py:39-40, :298
+//   y = normalize_2nd_moment(embed(c))                            :301 (FullyConnectedLayer, linear)
+//   x = cat([x, y]); for idx in range(num_layers): x = fc{idx}(x) :302-307 (lrelu, lr_multiplier 0.01: weight_gain =
+//                                                                  lr / sqrt(in), bias_gain = lr; bias_act gain sqrt(2))
+//   ws = x.unsqueeze(1).repeat(1, num_ws, 1)                      :315-316
+//   ws[:, :cutoff] = w_avg.lerp(ws[:, :cutoff], psi)              :319-324
+// which the framework runs as 9 small GEMMs + ~20 element-wise launches: ~30 dependent 4-8 us kernels with a gap after
+// each, 300 us at the head of every synthesis pass (rocprofv3 trace of bench.py) for 8.4 MB of weights.
+//
+// One kernel, MAP_WGS workgroups of 256 threads: every workgroup keeps the current activation vector of all images in LDS
+// and computes a slice of each layer's outputs (a wave = a few rows, lanes split K with 16-byte loads, all rows of a 256-column
+// slab requested before any is used: the GEMV is latency-bound); the new activations go through a global buffer and a
+// grid-wide barrier (monotonic atomic counter — all MAP_WGS workgroups are co-resident: 64 << 256 CUs x occupancy).
+#include "common.h"
+
+namespace ide3d {
+namespace {
+
+constexpr int MAP_WGS = 64;
+constexpr int MAP_MAX_N = 8;            // images per launch (LDS: MAP_MAX_N x MAP_MAX_K floats)
+constexpr int MAP_NB = 4;               // images per register block of the GEMV
+constexpr int MAP_MAX_K = 1024;
+constexpr int MAP_MAX_LAYERS = 16;
+
+struct MapArgs {
+    const float* z; const float* c;
+    const float* embed_w; const float* embed_b;            // [embed, c_dim], [embed]
+    const float* fc_w[MAP_MAX_LAYERS]; const float* fc_b[MAP_MAX_LAYERS];
+    int fc_in[MAP_MAX_LAYERS], fc_out[MAP_MAX_LAYERS];
+    const float* w_avg;
+    float* act;                                             // [2][n][MAP_MAX_K] ping-pong
+    unsigned* counter;                                      // zeroed by the host before the launch
+    float* ws;                                              // [n, num_ws, w_dim]
+    int n, z_dim, c_dim, embed, layers, num_ws;
+    float embed_wgain, embed_bgain, lr_mul, alpha, act_gain, psi;
+    int cutoff;                                             // layers [0, cutoff) are truncated (num_ws = all)
+};
+
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(counter, 1u);
+        while (__atomic_load_n(counter, __ATOMIC_ACQUIRE) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+// rows [r0, r1) of  out[n, r] = act(sum_k x[n, k] * W[r, k] * wg + b[r] * bg)  for all n; x in LDS [n][K]
+template <int RB>
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ s_x, int n, int K, const float* __restrict__ W, const float* __restrict__ b,
+                                          int r0, int r1, float wg, float bg, float alpha, float gain, float* __restrict__ out, int out_pitch) {
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i0 = r0 + wid * RB; i0 < r1; i0 += nw * RB)
+    for (int m0 = 0; m0 < n; m0 += MAP_NB) {              // images in register blocks of MAP_NB (weights re-read from L2 per block)
+        float acc[RB][MAP_NB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int m = 0; m < MAP_NB; ++m) acc[r][m] = 0.f;
+        for (int k = lane * 4; k < K; k += kWave * 4) {
+            float4 a[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(W + (int64_t)min(i0 + r, r1 - 1) * K + k);
+#pragma unroll
+            for (int m = 0; m < MAP_NB; ++m) {
+                const float4 xk = *reinterpret_cast<const float4*>(s_x + min(m0 + m, n - 1) * MAP_MAX_K + k);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r][m] += (a[r].x * xk.x + a[r].y * xk.y) + (a[r].z * xk.z + a[r].w * xk.w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int m = 0; m < MAP_NB; ++m) {
+                float v = acc[r][m];
+#pragma unroll
+                for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                const int i = i0 + r;
+                if (lane == 0 && i < r1 && m0 + m < n) {
+                    v = v * wg + (b ? b[i] * bg : 0.f);
+                    v = (v > 0.f ? v : v * alpha) * gain;
+                    out[(m0 + m) * out_pitch + i] = v;
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(256)
+mapping_kernel(const MapArgs p) {
+    __shared__ __attribute__((aligned(16))) float s_x[MAP_MAX_N * MAP_MAX_K];
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    // ---- input stage (redundantly in every workgroup: 512 + 512 x 25 multiply-adds per image) ----
+    const int K0 = p.z_dim + p.embed;
+    for (int m = 0; m < p.n; ++m) {
+        float sq = 0.f;
+        for (int k = tid; k < p.z_dim; k += blockDim.x) { const float v = p.z[m * p.z_dim + k]; sq += v * v; }
+        const float zs = (p.z_dim > 0) ? rsqrtf(block_sum(sq, s_red) / (float)p.z_dim + 1e-8f) : 0.f;
+        for (int k = tid; k < p.z_dim; k += blockDim.x) s_x[m * MAP_MAX_K + k] = p.z[m * p.z_dim + k] * zs;
+        float sq2 = 0.f;
+        for (int e = tid; e < p.embed; e += blockDim.x) {
+            float acc = 0.f;
+            for (int k = 0; k < p.c_dim; ++k) acc += p.c[m * p.c_dim + k] * p.embed_w[e * p.c_dim + k];
+            const float v = acc * p.embed_wgain + (p.embed_b ? p.embed_b[e] * p.embed_bgain : 0.f);
+            s_x[m * MAP_MAX_K + p.z_dim + e] = v; sq2 += v * v;
+        }
+        const float es = (p.embed > 0) ? rsqrtf(block_sum(sq2, s_red) / (float)p.embed + 1e-8f) : 0.f;
+        for (int e = tid; e < p.embed; e += blockDim.x) s_x[m * MAP_MAX_K + p.z_dim + e] *= es;
+    }
+    __syncthreads();
+    // ---- layers ----
+    int K = K0;
+    for (int l = 0; l < p.layers; ++l) {
+        const int O = p.fc_out[l];
+        const int per = cdiv(O, nwg), r0 = wg * per, r1 = min(O, r0 + per);
+        float* out = p.act + (size_t)(l & 1) * MAP_MAX_N * MAP_MAX_K;
+        if (r0 < r1)
+            gemv_rows<2>(s_x, p.n, K, p.fc_w[l], p.fc_b[l], r0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
+        grid_barrier(p.counter, (unsigned)(l + 1) * nwg);
+        for (int i = tid; i < p.n * O; i += blockDim.x) { const int m = i / O, k = i - m * O; s_x[m * MAP_MAX_K + k] = __hip_atomic_load(&out[m * MAP_MAX_K + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // written by other CUs: not through this CU's L1
+        __syncthreads();
+        K = O;
+    }
+    // ---- broadcast + truncation: this workgroup writes its share of the [n, num_ws] rows ----
+    const int rows = p.n * p.num_ws;
+    for (int row = wg; row < rows; row += nwg) {
+        const int m = row / p.num_ws, j = row - m * p.num_ws;
+        const bool trunc = (p.psi != 1.0f) && j < p.cutoff;
+        for (int k = tid; k < K; k += blockDim.x) {
+            float v = s_x[m * MAP_MAX_K + k];
+            if (trunc) {                                                               // torch.lerp(w_avg, v, psi), ATen's two-sided formula
+                const float a = p.w_avg[k], d = v - a;
+                v = (fabsf(p.psi) < 0.5f) ? a + p.psi * d : v - d * (1.0f - p.psi);
+            }
+            p.ws[(size_t)row * K + k] = v;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace ide3d
+
+extern "C" int ide3d_mapping_workspace_bytes(void) {
+    return (int)(2 * ide3d::MAP_MAX_N * ide3d::MAP_MAX_K * sizeof(float) + 256);
+}
+
+extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(q != nullptr, "mapping: null params");
+    IDE3D_CHECK_ARG(q->n > 0 && q->n <= MAP_MAX_N, "mapping: batch must be 1..%d (got %d)", MAP_MAX_N, q->n);
+    IDE3D_CHECK_ARG(q->layers >= 1 && q->layers <= MAP_MAX_LAYERS, "mapping: 1..%d layers", MAP_MAX_LAYERS);
+    IDE3D_CHECK_ARG(q->z_dim >= 0 && q->embed >= 0 && q->z_dim + q->embed > 0 && q->z_dim + q->embed <= MAP_MAX_K && (q->z_dim + q->embed) % 4 == 0,
+                    "mapping: z_dim + embed must be a multiple of 4, at most %d", MAP_MAX_K);
+    IDE3D_CHECK_ARG((q->z_dim == 0 || q->z) && (q->embed == 0 || (q->c && q->embed_w && q->c_dim > 0)), "mapping: null input pointer");
+    IDE3D_CHECK_ARG(q->ws && q->workspace && q->workspace_bytes >= ide3d_mapping_workspace_bytes(), "mapping: null output / workspace too small");
+    IDE3D_CHECK_ARG(q->num_ws >= 1, "mapping: num_ws must be positive");
+    IDE3D_CHECK_ARG(q->truncation_psi == 1.0f || q->w_avg, "mapping: truncation needs w_avg");
+    MapArgs a{};
+    a.z = q->z; a.c = q->c; a.embed_w = q->embed_w; a.embed_b = q->embed_b;
+    int k = q->z_dim + q->embed;
+    for (int l = 0; l < q->layers; ++l) {
+        IDE3D_CHECK_ARG(q->fc_w[l] && q->fc_out[l] > 0 && q->fc_out[l] <= MAP_MAX_K && q->fc_out[l] % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(q->fc_w[l]) & 15) == 0), "mapping: layer %d: bad weight / width", l);
+        a.fc_w[l] = q->fc_w[l]; a.fc_b[l] = q->fc_b[l]; a.fc_in[l] = k; a.fc_out[l] = q->fc_out[l];
+        k = q->fc_out[l];
+    }
+    a.w_avg = q->w_avg;
+    a.act = reinterpret_cast<float*>(q->workspace);
+    a.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(q->workspace) + 2 * MAP_MAX_N * MAP_MAX_K * sizeof(float));
+    a.ws = q->ws;
+    a.n = q->n; a.z_dim = q->z_dim; a.c_dim = q->c_dim; a.embed = q->embed; a.layers = q->layers; a.num_ws = q->num_ws;
+    a.embed_wgain = q->embed_weight_gain; a.embed_bgain = q->embed_bias_gain; a.lr_mul = q->lr_multiplier;
+    a.alpha = q->alpha; a.act_gain = q->act_gain; a.psi = q->truncation_psi;
+    a.cutoff = (q->truncation_cutoff < 0) ? q->num_ws : q->truncation_cutoff;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(a.counter, 0, sizeof(unsigned), st) != hipSuccess) { set_error("mapping: hipMemsetAsync failed"); return IDE3D_ELAUNCH; }
+    hipLaunchKernelGGL(mapping_kernel, dim3(MAP_WGS), dim3(256), 0, st, a);
+    IDE3D_CHECK_LAUNCH("mapping");
+    return IDE3D_OK;
+}

@@ -60,15 +60,16 @@ template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9
 // patch and all 9 taps (each tap feeds exactly one class), i.e. 4x the MFMA work per staging step / barrier of mode 2.
 template <> struct ModeCfg<MODE_TCONV3A> { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 
-template <int MODE, int BIG, int TI, int PH, int PW>
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4>
 struct McCfg {
+    static constexpr int NT = 64 * NWV;                     // threads per workgroup (4 or 8 waves)
     static constexpr int BN = TI * PH * PW;
     static_assert(BN == 64 || BN == 128 || BN == 256, "pixel tile must hold 64, 128 or 256 pixels");
     static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;   // accumulator sets (output parity classes)
     using MC = ModeCfg<MODE>;
     static constexpr int KC = MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
     // BIG: 1 -> BM 128 (waves 2 x 2, two M tiles each); 2 -> BM 64 (waves 2 x 2, one M tile each); 0 -> BM 32 (waves 1 x 4)
-    static constexpr int WM = BIG ? 2 : 1, WN = 4 / WM;
+    static constexpr int WM = BIG ? 2 : 1, WN = NWV / WM;
     static constexpr int MTW = (BIG == 1) ? 2 : 1;          // 32-row M tiles per wave
     static constexpr int NTW = (BN / 32) / WN;              // 32-pixel N tiles per wave
     static constexpr int BM = WM * MTW * 32;
@@ -82,10 +83,10 @@ struct McCfg {
     static constexpr int XI = KC * XS;                      // per-image pitch
     static constexpr int LDS_W = MAXT * KC * BM;            // floats, one buffer
     static constexpr int LDS_X = TI * XI;
-    static constexpr int NW4 = (LDS_W / 4 + 255) / 256;     // float4 weight loads per thread per chunk
+    static constexpr int NW4 = (LDS_W / 4 + NT - 1) / NT;   // float4 weight loads per thread per chunk
     // flat 1x1 tiles (one row of PW pixels, no halo) stage the patch in 16-byte pieces
     static constexpr int VW = (MODE == MODE_CONV1 && PH == 1 && PW % 4 == 0) ? 4 : 1;
-    static constexpr int NXE = (TI * KC * HP * HW / VW + 255) / 256;   // input elements (VW floats each) per thread per chunk
+    static constexpr int NXE = (TI * KC * HP * HW / VW + NT - 1) / NT;   // input elements (VW floats each) per thread per chunk
 };
 
 template <int N>
@@ -166,11 +167,11 @@ __host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3
 
 // One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
 // (MODE_TCONV3 only).  s_w / s_x: two buffers of K::LDS_W / K::LDS_X floats.
-template <int MODE, int BIG, int TI, int PH, int PW>
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV>
 __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, const float* __restrict__ wp, float* __restrict__ partial,
                                              const ConvGeom& g, float* s_w, float* s_x, int mb, int tl, int grp, int split, int cls,
                                              int tiles_x) {
-    using K = McCfg<MODE, BIG, TI, PH, PW>;
+    using K = McCfg<MODE, BIG, TI, PH, PW, NWV>;
 #ifdef IDE3D_MC_TRACE
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
@@ -217,7 +218,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     int x_src[K::NXE], x_dst[K::NXE], x_img[K::NXE];
 #pragma unroll
     for (int i = 0; i < K::NXE; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * K::NT;
         x_src[i] = -1; x_dst[i] = -1; x_img[i] = 0;
         if (e < TI * K::KC * K::HP * K::HW / K::VW) {
             int r = e;
@@ -275,7 +276,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
 #endif
     auto fetch = [&](int c, int buf) {
         const float* ws = wsrc + (int64_t)c * (K::WTAPS * K::KC * K::BM);
-        for (int i = wid; i < w_pieces; i += 4) {
+        for (int i = wid; i < w_pieces; i += NWV) {
             const int t = i / PPT, r = (i - t * PPT) * PIECE;
             const float* src = ws + ((MODE == MODE_TCONV3) ? sel(t_widx, t) : t) * (K::KC * K::BM) + r + lane * 4;
             if (lane * 4 < PIECE)
@@ -403,7 +404,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     // store exposes its latency that many times (measured: the epilogue took as long as 7 - 60 K chunks).
     float* const s_dm = s_w;                       // [TI][BM]
     float* const s_bi = s_w + TI * K::BM;          // [BM]
-    for (int e = tid; e < TI * K::BM; e += 256) {
+    for (int e = tid; e < TI * K::BM; e += K::NT) {
         const int rl = e % K::BM, co = mb * K::BM + rl, n = min(n0 + e / K::BM, p.n - 1);
         s_dm[e] = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
         if (e < K::BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
@@ -428,7 +429,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
     constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = K::NCLS / QX;
     constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
     constexpr int AVAIL = 2 * K::LDS_W - (TI + 1) * K::BM;
-    constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= 4 * 32 * TP) ? 32 : (AVAIL >= 4 * 16 * TP) ? 16 : (AVAIL >= 4 * 8 * TP) ? 8 : 0;
+    constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= NWV * 32 * TP) ? 32 : (AVAIL >= NWV * 16 * TP) ? 16 : (AVAIL >= NWV * 8 * TP) ? 8 : 0;
     if constexpr (RR > 0) {
         typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
         float* const T = s_w + (TI + 1) * K::BM + wid * (RR * TP);
@@ -522,18 +523,21 @@ __device__ __forceinline__ BlockId decode_block(const ConvGeom& g) {
     return b;
 }
 
-template <int MODE, int BIG, int TI, int PH, int PW>
-// 128-pixel (and smaller) tiles: <= 168 VGPRs and <= 53 KB of LDS, three workgroups per CU (measured +2 % frames/s over two);
-// the stride-2 mode's (2P + 1) x (2Q + 1) patches need more LDS than that
-__global__ void __launch_bounds__(256, (TI * PH * PW <= 128 && MODE != MODE_CONV3S2) ? 3 : 2)
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4>
+// 4-wave workgroups: 128-pixel (and smaller) tiles need <= 168 VGPRs and <= 53 KB of LDS, three workgroups per CU (measured +2 %
+// frames/s over two); the stride-2 mode's (2P + 1) x (2Q + 1) patches need more LDS than that; 16 accumulators per wave take
+// AGPRs and one workgroup per CU.  8-wave workgroups: one per CU, two waves per SIMD.
+__global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 2
+                                  : (McCfg<MODE, BIG, TI, PH, PW, NWV>::NCLS * McCfg<MODE, BIG, TI, PH, PW, NWV>::MTW * McCfg<MODE, BIG, TI, PH, PW, NWV>::NTW > 8) ? 1
+                                  : (TI * PH * PW <= 128 && MODE != MODE_CONV3S2) ? 3 : 2)
 modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
-    using K = McCfg<MODE, BIG, TI, PH, PW>;
+    using K = McCfg<MODE, BIG, TI, PH, PW, NWV>;
     __shared__ __attribute__((aligned(16))) float s_w[2 * K::LDS_W];
     __shared__ __attribute__((aligned(16))) float s_x[2 * K::LDS_X];
     const BlockId b = decode_block(g);
     int cls = 0;
     if (MODE == MODE_TCONV3) { cls = (b.tile >= g.tile_base[1]) + (b.tile >= g.tile_base[2]) + (b.tile >= g.tile_base[3]); }
-    modconv_tile<MODE, BIG, TI, PH, PW>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
+    modconv_tile<MODE, BIG, TI, PH, PW, NWV>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
 }
 
 // reduce split-K partials + epilogue
@@ -571,11 +575,12 @@ struct ConvPlan {
 // Developer knobs (read once): IDE3D_MODCONV_NO_FLAT / _NO_TCONV3A switch the flattened 1x1 tiles / the all-class
 // transposed kernel off, IDE3D_MODCONV_TILE forces a pixel tile (0..3), IDE3D_MODCONV_DEBUG = 1 drops the staging after
 // the first chunk (timing experiments; wrong results).
-struct McEnv { bool no_flat, no_allcls; int tile, debug; };
+struct McEnv { bool no_flat, no_allcls; int tile, debug, ta_rows; };
 static const McEnv& mc_env() {
     static const McEnv e = {getenv("IDE3D_MODCONV_NO_FLAT") != nullptr, getenv("IDE3D_MODCONV_NO_TCONV3A") != nullptr,
                             getenv("IDE3D_MODCONV_TILE") ? atoi(getenv("IDE3D_MODCONV_TILE")) : -1,
-                            getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0};
+                            getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0,
+                            getenv("IDE3D_MODCONV_TA_ROWS") ? atoi(getenv("IDE3D_MODCONV_TA_ROWS")) : 0};
     return e;
 }
 
@@ -592,7 +597,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
-    pl.bm = mc_bm(p.cout); pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
+    pl.bm = mc_bm(p.cout);
+    if (allcls && pl.bm == 128 && mc_env().ta_rows == 64) pl.bm = 64;          // experiment: smaller M blocks (wave quantisation)
+    pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
     const bool transposed = (pl.mode == MODE_TCONV3 || pl.mode == MODE_TCONV3A);
@@ -616,9 +623,21 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (blocks256 >= 2 * kNumCU) pl.tile = 3;
     }
     if (mc_env().tile >= 0) { const int t = mc_env().tile; if (t >= 0 && t <= 3 && (t == 0 || t == 3 || !p.w_batch_stride)) pl.tile = (t == 3 && (pl.big != 1 || pl.mode == MODE_CONV1 || pl.mode == MODE_CONV3S2)) ? 0 : t; }
-    if (pl.mode == MODE_TCONV3A) pl.tile = 4;                       // 64 grid positions (4 x 16) x 4 classes per block
+    if (pl.mode == MODE_TCONV3A) {
+        // grid positions per block x 4 classes: 4 x 16 (8 accumulators per wave at BM = 128, two or three workgroups per CU) or —
+        // the weight slab of a K chunk (18 KB at BM = 128) is streamed L2 -> LDS once per chunk and per block, and that stream
+        // (~11 B/clk/CU) is what bounds the small tile — 8 x 16 / 16 x 16 positions with 16 accumulators per wave (AGPRs, one
+        // workgroup per CU): twice the MFMAs per streamed weight byte
+        pl.tile = 4;
+        const int rows = mc_env().ta_rows ? mc_env().ta_rows : 0;
+        if (rows == 8 && pl.big == 1) pl.tile = 6;
+        if (rows == 16 && pl.big == 2) pl.tile = 7;
+        if (rows == 8 && pl.big == 2) pl.tile = 6;
+        // 512-thread workgroups: 8 x 16 positions at BM = 128, 16 x 16 at BM = 64 (8 accumulators per wave either way)
+        if (rows == 108) pl.tile = (pl.big == 1) ? 8 : 9;
+    }
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
-    static const int TIv[6] = {1, 2, 8, 1, 1, 1}, PHv[6] = {8, 8, 4, 16, 4, 1}, PWv[6] = {16, 8, 4, 16, 16, 128};
+    static const int TIv[10] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1}, PHv[10] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16}, PWv[10] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -646,8 +665,13 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     if constexpr (MODE == MODE_TCONV3A) {
-        if constexpr (BIG != 0)
-            hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+        if constexpr (BIG != 0) {
+            if (pl.tile == 8) { if constexpr (BIG == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16, 8>), dim3(nblocks), dim3(512), 0, st, p, wp, partial, g); }
+            else if (pl.tile == 9) { if constexpr (BIG == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16, 8>), dim3(nblocks), dim3(512), 0, st, p, wp, partial, g); }
+            else if (pl.tile == 6) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+            else if (pl.tile == 7) { if constexpr (BIG == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g); }
+            else hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 4, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
+        }
     } else
     if (pl.tile == 5) {
         if constexpr (MODE == MODE_CONV1)

@@ -118,15 +118,12 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ pb, co
 
 // Two-layer MLP on a 16-sample tile, transposed MFMA form.  out[mt][r] = feature 16 mt + 4 g + r of sample j.
 template <int C, int HID>
-__device__ __forceinline__ void mlp_tile(const float* __restrict__ s, const float (&f)[C / 4], f32x4 (&out)[2]) {
+__device__ __forceinline__ void mlp_hidden(const float* __restrict__ s, const float (&f)[C / 4], f32x4 (&h)[HID / 16]) {
     using K = RmCfg<C, HID>;
     const int lane = lane_id();
     const f32x4* a1 = reinterpret_cast<const f32x4*>(s);
-    const f32x4* a2 = reinterpret_cast<const f32x4*>(s + K::A1);
     const f32x4* sb0 = reinterpret_cast<const f32x4*>(s + K::A1 + K::A2);
-    const f32x4* sb1 = reinterpret_cast<const f32x4*>(s + K::A1 + K::A2 + K::B0);
     const int g = lane >> 4;
-    f32x4 h[K::MT1];
 #pragma unroll
     for (int mt = 0; mt < K::MT1; ++mt) h[mt] = sb0[mt * 4 + g];
 #pragma unroll
@@ -144,6 +141,17 @@ __device__ __forceinline__ void mlp_tile(const float* __restrict__ s, const floa
     for (int mt = 0; mt < K::MT1; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[mt][r] = softplus_fast(h[mt][r]);
+}
+
+template <int C, int HID>
+__device__ __forceinline__ void mlp_tile(const float* __restrict__ s, const float (&f)[C / 4], f32x4 (&out)[2]) {
+    using K = RmCfg<C, HID>;
+    const int lane = lane_id();
+    const f32x4* a2 = reinterpret_cast<const f32x4*>(s + K::A1);
+    const f32x4* sb1 = reinterpret_cast<const f32x4*>(s + K::A1 + K::A2 + K::B0);
+    const int g = lane >> 4;
+    f32x4 h[K::MT1];
+    mlp_hidden<C, HID>(s, f, h);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) out[mt] = sb1[mt * 4 + g];
 #pragma unroll
@@ -156,6 +164,28 @@ __device__ __forceinline__ void mlp_tile(const float* __restrict__ s, const floa
             out[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], h[tq][e], out[1], 0, 0, 0);
         }
     }
+}
+
+// Density only: of the second layer just row 0 (sigma) is needed — a 64-term dot product per sample.  The hidden vector of a
+// sample is spread over its four lanes (lane (g, j) holds units 16 mt + 4 g + r), so each lane forms a 16-term partial sum on
+// the VALU and two xor-shuffles across g close it: ~20 vector instructions instead of the 32 MFMAs (1024 cycles) of the
+// 32-row layer.  s_row: w1[0][0..HID) followed by b1[0].
+template <int C, int HID>
+__device__ __forceinline__ float mlp_sigma(const float* __restrict__ s, const float* __restrict__ s_row, const float (&f)[C / 4]) {
+    using K = RmCfg<C, HID>;
+    const int g = lane_id() >> 4;
+    f32x4 h[K::MT1];
+    mlp_hidden<C, HID>(s, f, h);
+    float acc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(s_row + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += w[r] * h[mt][r];
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    return acc + s_row[HID];
 }
 
 __device__ __forceinline__ float seg16_excl_prod(float v, float& total) {
@@ -337,6 +367,10 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     float* s_stage = lds + 2 * K::MLP;                 // [4 waves][16 samples][width] row staging
     stage_mlp<C, HID>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
     if (!sigma_only) stage_mlp<C, HID>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
+    float* const s_row = s_tex;                        // sigma-only: row 0 of geo_w1 + its bias live where the texture MLP would
+    if (sigma_only) {
+        for (int i = threadIdx.x; i <= HID; i += blockDim.x) s_row[i] = (i < HID) ? p.geo_w1[i] : p.geo_b1[0];
+    }
     __syncthreads();
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int g = lane >> 4, j = lane & 15;
@@ -361,12 +395,13 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
                                make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
         float fg[K::NF];
         gather_features<C>(p.geo_planes + n * p.geo_stride[0], t, g, fg);
-        f32x4 og[2];
-        mlp_tile<C, HID>(s_geo, fg, og);
         if (sigma_only) {
-            if (g == 0 && live) out_sigma[row] = og[0][0];
+            const float sig = mlp_sigma<C, HID>(s_geo, s_row, fg);
+            if (g == 0 && live) out_sigma[row] = sig;
             continue;
         }
+        f32x4 og[2];
+        mlp_tile<C, HID>(s_geo, fg, og);
         float ft[K::NF];
         gather_features<C>(p.tex_planes + n * p.tex_stride[0], t, g, ft);
         f32x4 ot[2];

@@ -119,6 +119,20 @@ class _ModconvParams(ctypes.Structure):
     ]
 
 
+class _MappingParams(ctypes.Structure):
+    _fields_ = [
+        ('z', ctypes.c_void_p), ('c', ctypes.c_void_p), ('embed_w', ctypes.c_void_p), ('embed_b', ctypes.c_void_p),
+        ('fc_w', ctypes.c_void_p * 16), ('fc_b', ctypes.c_void_p * 16), ('fc_out', ctypes.c_int32 * 16),
+        ('w_avg', ctypes.c_void_p), ('ws', ctypes.c_void_p),
+        ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
+        ('n', ctypes.c_int32), ('z_dim', ctypes.c_int32), ('c_dim', ctypes.c_int32), ('embed', ctypes.c_int32),
+        ('layers', ctypes.c_int32), ('num_ws', ctypes.c_int32),
+        ('embed_weight_gain', ctypes.c_float), ('embed_bias_gain', ctypes.c_float), ('lr_multiplier', ctypes.c_float),
+        ('alpha', ctypes.c_float), ('act_gain', ctypes.c_float), ('truncation_psi', ctypes.c_float),
+        ('truncation_cutoff', ctypes.c_int32),
+    ]
+
+
 def _hip_runtimes_mapped():
     """Paths of every libamdhip64 mapped into this process (there must be exactly one)."""
     paths = set()
@@ -186,6 +200,10 @@ def load():
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
             'ide3d_style_demod': [vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp],
             'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
+            'ide3d_mapping': [ctypes.POINTER(_MappingParams), vp],
+            'ide3d_mapping_workspace_bytes': [],
+            'ide3d_skip_upsample_add_cl': [vp, ctypes.POINTER(i64 * 4), vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, vp],
+            'ide3d_bilinear_up2_split': [vp, i32, i32, i32, i32, ctypes.POINTER(vp * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(i32 * 3), vp],
         }
         for name, argtypes in protos.items():
             fn = getattr(lib, name)          # AttributeError here = header / library mismatch
@@ -201,6 +219,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
+    'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes',
 )
 
 
@@ -788,6 +807,85 @@ class FramePlugin:
         return out
 
 
+class MappingPlugin:
+    MAX_N, MAX_WIDTH, MAX_LAYERS = 8, 1024, 16
+    _ws = {}          # (device index, stream) -> workspace tensor (activation ping-pong + barrier counter), never freed
+
+    @staticmethod
+    def supports(n, z_dim, embed, widths):
+        k0 = z_dim + embed
+        return (1 <= n <= MappingPlugin.MAX_N and 0 < k0 <= MappingPlugin.MAX_WIDTH and k0 % 4 == 0 and 1 <= len(widths) <= MappingPlugin.MAX_LAYERS
+                and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths))
+
+    @staticmethod
+    def mapping(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff):
+        """z [n, z_dim], c [n, c_dim] | None, raw parameters of the embed / fc layers -> ws [n, num_ws, w_dim] (one launch)."""
+        dev = z.device
+        f32c = lambda t: t is None or (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous())
+        _require(all(f32c(t) for t in (z, c, embed_w, embed_b, w_avg, *fc_ws, *fc_bs)), 'mapping: contiguous float32 tensors on one CUDA device required')
+        n, z_dim = z.shape
+        embed = 0 if embed_w is None else embed_w.shape[0]
+        _require(MappingPlugin.supports(n, z_dim, embed, [w.shape[0] for w in fc_ws]), 'mapping: unsupported shape')
+        k = z_dim + embed
+        for w, b in zip(fc_ws, fc_bs):
+            _require(w.ndim == 2 and w.shape[1] == k and (b is None or tuple(b.shape) == (w.shape[0],)), 'mapping: layer widths do not chain')
+            k = w.shape[0]
+        lib = load()
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        wsp = MappingPlugin._ws.get(key)
+        if wsp is None:
+            wsp = MappingPlugin._ws[key] = torch.zeros([lib.ide3d_mapping_workspace_bytes() // 4 + 4], dtype=torch.float32, device=dev)
+        out = torch.empty([n, num_ws, k], dtype=torch.float32, device=dev)
+        p = _MappingParams()
+        p.z, p.c = z.data_ptr(), (c.data_ptr() if c is not None else 0)
+        p.embed_w, p.embed_b = (embed_w.data_ptr() if embed_w is not None else 0), (embed_b.data_ptr() if embed_b is not None else 0)
+        for i, (w, b) in enumerate(zip(fc_ws, fc_bs)):
+            p.fc_w[i], p.fc_b[i], p.fc_out[i] = w.data_ptr(), (b.data_ptr() if b is not None else 0), w.shape[0]
+        p.w_avg = w_avg.data_ptr() if w_avg is not None else 0
+        p.ws, p.workspace, p.workspace_bytes = out.data_ptr(), wsp.data_ptr(), wsp.numel() * 4
+        p.n, p.z_dim, p.c_dim, p.embed, p.layers, p.num_ws = n, z_dim, (c.shape[1] if c is not None else 0), embed, len(fc_ws), num_ws
+        p.embed_weight_gain, p.embed_bias_gain, p.lr_multiplier = float(embed_wgain), float(embed_bgain), float(lr_multiplier)
+        p.alpha, p.act_gain, p.truncation_psi = float(alpha), float(act_gain), float(psi)
+        p.truncation_cutoff = -1 if cutoff is None else int(cutoff)
+        with torch.cuda.device(dev):
+            rc = lib.ide3d_mapping(ctypes.byref(p), _stream(z))
+        _check(rc, 'mapping')
+        return out
+
+
+class ResamplePlugin:
+    @staticmethod
+    def skip_upsample_add_cl(lo, add):
+        """upsample2d(lo, [1,3,3,1]) + add -> [n, c, 2h, 2w] in channels_last memory format (lo / add: any strides)."""
+        _require(lo.is_cuda and lo.dtype == torch.float32 and add.dtype == torch.float32 and add.device == lo.device,
+                 'skip_upsample_add_cl: float32 CUDA tensors on one device required')
+        n, c, h, w = lo.shape
+        _require(tuple(add.shape) == (n, c, 2 * h, 2 * w), 'skip_upsample_add_cl: add must be [n, c, 2h, 2w]')
+        _require(c % 4 == 0, 'skip_upsample_add_cl: channel count must be a multiple of 4')
+        out = torch.empty([n, c, 2 * h, 2 * w], dtype=torch.float32, device=lo.device, memory_format=torch.channels_last)
+        with torch.cuda.device(lo.device):
+            rc = load().ide3d_skip_upsample_add_cl(_ptr(lo), ctypes.byref(_i64x4(lo.stride())), _ptr(add), ctypes.byref(_i64x4(add.stride())),
+                                                   n, c, h, w, _ptr(out), _stream(lo))
+        _check(rc, 'skip_upsample_add_cl')
+        return out
+
+    @staticmethod
+    def bilinear_up2_split(x, ranges):
+        """x [n, c, h, w] -> one [n, count, 2h, 2w] tensor per (begin, count) in `ranges` (at most 3), bilinear, align_corners=False."""
+        _require(x.is_cuda and x.dtype == torch.float32, 'bilinear_up2_split: float32 CUDA tensor required')
+        _require(1 <= len(ranges) <= 3, 'bilinear_up2_split: one to three channel ranges')
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        outs = [torch.empty([n, cnt, 2 * h, 2 * w], dtype=torch.float32, device=x.device) for _b, cnt in ranges]
+        dst = (ctypes.c_void_p * 3)(*([o.data_ptr() for o in outs] + [0] * (3 - len(outs))))
+        beg = (ctypes.c_int32 * 3)(*([int(b) for b, _c in ranges] + [0] * (3 - len(outs))))
+        cnt = (ctypes.c_int32 * 3)(*([int(c_) for _b, c_ in ranges] + [0] * (3 - len(outs))))
+        with torch.cuda.device(x.device):
+            rc = load().ide3d_bilinear_up2_split(_ptr(x), n, c, h, w, ctypes.byref(dst), ctypes.byref(beg), ctypes.byref(cnt), _stream(x))
+        _check(rc, 'bilinear_up2_split')
+        return outs
+
+
 PLUGINS = {
     'bias_act_plugin': BiasActPlugin,
     'upfirdn2d_plugin': Upfirdn2dPlugin,
@@ -797,4 +895,6 @@ PLUGINS = {
     'modconv_plugin': ModconvPlugin,
     'frame_plugin': FramePlugin,
     'style_plugin': StylePlugin,
+    'resample_plugin': ResamplePlugin,
+    'mapping_plugin': MappingPlugin,
 }

@@ -41,6 +41,15 @@ def _upfirdn_plugin():
 
 
 _style_plugin = None
+_resample_plugin = None
+_mapping_plugin = None
+
+
+def _resample_init():
+    global _resample_plugin
+    if _resample_plugin is None:
+        _resample_plugin = custom_ops.get_plugin(module_name='resample_plugin', sources=['resample.hip'])
+    return True
 
 
 def _style_init():
@@ -485,10 +494,44 @@ class MappingNetwork(torch.nn.Module):
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
+    def _forward_hip(self, z, c, truncation_psi, truncation_cutoff):
+        """The whole network in ONE launch of csrc/mapping.hip (inference on device tensors, batch <= 8), or None."""
+        global _mapping_plugin
+        if self.z_dim == 0 or self.num_ws is None or not (z.device.type == 'cuda' and not torch.is_grad_enabled()):
+            return None
+        layers = [getattr(self, f'fc{i}') for i in range(self.num_layers)]
+        embed = self.embed if self.c_dim > 0 else None
+        if any(l.activation != 'lrelu' or l.weight.dtype != torch.float32 or l.bias_gain != layers[0].bias_gain
+               or not np.isclose(l.weight_gain * np.sqrt(l.weight.shape[1]), l.bias_gain, rtol=1e-6) for l in layers):      # one lr_multiplier
+            return None
+        if embed is not None and (embed.activation != 'linear' or c is None):
+            return None
+        if _mapping_plugin is None:
+            _mapping_plugin = custom_ops.get_plugin(module_name='mapping_plugin', sources=['mapping.hip'])
+        if not _mapping_plugin.supports(z.shape[0], self.z_dim, 0 if embed is None else embed.weight.shape[0], [l.weight.shape[0] for l in layers]):
+            return None
+        if truncation_psi != 1 and self.w_avg_beta is None:
+            return None
+        spec = bias_act.activation_funcs['lrelu']
+        zc = z.to(torch.float32).contiguous()
+        cc = None if embed is None else c.to(torch.float32).contiguous()
+        return _mapping_plugin.mapping(
+            zc, cc, None if embed is None else embed.weight, None if embed is None else embed.bias,
+            1.0 if embed is None else embed.weight_gain, 1.0 if embed is None else embed.bias_gain,
+            [l.weight for l in layers], [l.bias for l in layers], layers[0].bias_gain, spec.def_alpha, spec.def_gain,
+            self.num_ws, self.w_avg if (self.w_avg_beta is not None) else None, float(truncation_psi), truncation_cutoff)
+
     def forward(self, z=None, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False, styles=None,
                 **unused_kwargs):
         if styles is not None:
             return styles
+        if z is not None and not self.training:
+            misc.assert_shape(z, [None, self.z_dim])
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+            ws = self._forward_hip(z, c, truncation_psi, truncation_cutoff)
+            if ws is not None:
+                return ws
         x = None
         with torch.autograd.profiler.record_function('input'):
             if self.z_dim > 0:
@@ -672,11 +715,24 @@ class SegSynthesisBlock(torch.nn.Module):
         raise NotImplementedError
 
     def _accumulate(self, lo, cur, y):
-        """skip = upsample2d(lo) + y  (one HIP launch when `lo` is the deferred low-resolution skip image)."""
+        """skip = upsample2d(lo) + y  (one HIP launch when `lo` is the deferred low-resolution skip image).  A block flagged
+        `skip_channels_last` (the last tri-plane block: its skip images ARE the tri-planes the ray-marcher gathers from) gets
+        the result in channels_last memory format straight from the kernel (csrc/resample.hip) instead of NCHW + a transpose."""
         if lo is not None:
+            if (getattr(self, 'skip_channels_last', False) and lo.shape[1] % 4 == 0 and self.resample_filter.shape == (4, 4)
+                    and _inference_on_gpu(lo, y) and self._filter_is_1331() and _resample_init()):
+                return _resample_plugin.skip_upsample_add_cl(lo, y)
             f = self.resample_filter
             return _upfirdn_plugin().upfirdn2d_ex(lo, f, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0, add=y)
         return cur.add_(y) if cur is not None else y
+
+    def _filter_is_1331(self):
+        """The fused channels-last skip kernel hard-codes the [1,3,3,1] x [1,3,3,1] / 64 filter (checked once per module)."""
+        ok = getattr(self, '_f1331', None)
+        if ok is None:
+            ref = upfirdn2d.setup_filter([1, 3, 3, 1])
+            ok = self._f1331 = bool(torch.equal(self.resample_filter.detach().cpu(), ref))
+        return ok
 
     def forward(self, x, img, seg, ws, force_fp32=False, fused_modconv=None, block_noise=None, disable_rgb=False, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])

@@ -270,6 +270,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
             self.num_ws += block.num_conv
             setattr(self, f'vb{res}', block)
 
+        # the skip images of the last voxel block are the tri-planes: have them written channels-last (the gather layout)
+        getattr(self, f'vb{self.voxel_block_resolutions[-1]}').skip_channels_last = True
         self.renderer = TriplaneRenderer(spec)
         self.style_prefetch = True        # GPU inference: style kernels on a side stream (networks.prefetch_styles)
 
@@ -314,10 +316,15 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         """[N, feat+seg, R, R] composited features -> (img, seg) at full resolution."""
         fc = self.spec.feature_channels
         size = self.block_resolutions[0] // 2
-        up = lambda t: torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', align_corners=False)
-        x = up(feat[:, :fc])
-        img = up(feat[:, :self.img_channels])
-        seg = up(feat[:, fc:])
+        if (size == 2 * feat.shape[-1] and size == 2 * feat.shape[-2] and networks._inference_on_gpu(feat) and networks._resample_init()):
+            # one launch (csrc/resample.hip) instead of three ATen bilinear launches: same source-index rule and weights
+            x, img, seg = networks._resample_plugin.bilinear_up2_split(
+                feat, [(0, fc), (0, self.img_channels), (fc, feat.shape[1] - fc)])
+        else:
+            up = lambda t: torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', align_corners=False)
+            x = up(feat[:, :fc])
+            img = up(feat[:, :self.img_channels])
+            seg = up(feat[:, fc:])
         for res, cur_ws in zip(self.block_resolutions, block_ws):
             x, img, seg = getattr(self, f'b{res}')(x, img, seg, cur_ws, **block_kwargs)
         return img, seg

@@ -376,6 +376,54 @@ int ide3d_fold_heads(const float* w, int64_t w_stride, int32_t n, int32_t cin, i
                      float* out, void* stream);
 
 /* ---- output post-processing -------------------------------------------- */
+/* ---- mapping network ---------------------------------------------------------------------- */
+/*
+ * `MappingNetwork.forward` (inversion/networks.py:287-325) in one launch: normalize_2nd_moment(z), embed(c) + normalize,
+ * concat, `layers` x FullyConnectedLayer(lrelu, lr_multiplier), broadcast to num_ws, truncation towards w_avg.
+ * z [n, z_dim], c [n, c_dim], embed_w [embed, c_dim], fc_w[l] [fc_out[l], in_l] (in_0 = z_dim + embed, in_l = fc_out[l-1]):
+ * dense float32 with the RAW parameters; the runtime gains are applied here like FullyConnectedLayer does
+ * (weight_gain = lr_multiplier / sqrt(in), bias_gain = lr_multiplier; the embed layer's gains are passed explicitly).
+ * ws [n, num_ws, fc_out[layers-1]] is written.  truncation_psi == 1 disables truncation; truncation_cutoff < 0 = all layers.
+ * workspace: ide3d_mapping_workspace_bytes() bytes of device memory (activation ping-pong + barrier counter).
+ * n <= 8, widths <= 1024 and multiples of 4; returns IDE3D_EINVAL otherwise (callers then use their generic path).
+ */
+typedef struct ide3d_mapping_params {
+    const float* z; const float* c;
+    const float* embed_w; const float* embed_b;
+    const float* fc_w[16]; const float* fc_b[16];
+    int32_t fc_out[16];
+    const float* w_avg;
+    float* ws;
+    void* workspace; int64_t workspace_bytes;
+    int32_t n, z_dim, c_dim, embed, layers, num_ws;
+    float embed_weight_gain, embed_bias_gain, lr_multiplier, alpha, act_gain, truncation_psi;
+    int32_t truncation_cutoff;
+} ide3d_mapping_params;
+
+int ide3d_mapping_workspace_bytes(void);
+int ide3d_mapping(const ide3d_mapping_params* p, void* stream);
+
+/* ---- resampling between the big kernels of G.synthesis ---------------------------------- */
+/*
+ * out = upsample2d(lo, [1,3,3,1]) + add, written CHANNELS-LAST: the last skip accumulation of the tri-plane backbone
+ * (`img = upfirdn2d.upsample2d(img, resample_filter) + torgb(x)`, inversion/networks.py:1100-1111; upsample2d =
+ * upfirdn2d(up=2, pad (2,1,2,1), gain 4), torch_utils/ops/upfirdn2d.py:313-349) producing the layout the ray-marcher gathers
+ * from (32-channel texels = 128-byte lines) instead of NCHW + two transposing copies.
+ * lo [n, c, h, w] and add [n, c, 2h, 2w]: float32, element strides; out: float32 [n, 2h, 2w, c] dense (= a torch
+ * channels_last [n, c, 2h, 2w]), 16-byte aligned, c % 4 == 0.
+ */
+int ide3d_skip_upsample_add_cl(const float* lo, const int64_t lo_stride[4], const float* add, const int64_t add_stride[4],
+                               int32_t n, int32_t c, int32_t h, int32_t w, float* out, void* stream);
+
+/*
+ * torch.nn.functional.interpolate(x, scale 2, mode='bilinear', align_corners=False) of x [n, c, h, w] (dense NCHW float32),
+ * split into up to three dense NCHW outputs: dst[k] [n, c_count[k], 2h, 2w] takes input channels c_begin[k] ...
+ * (the composited 64x64 feature image -> colour features / raw RGB / semantic logits of the super-resolution blocks,
+ * SURVEY.md Appendix B; ATen source-index rule `area_pixel_compute_source_index`).  c_count[k] == 0 skips output k.
+ */
+int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, int32_t h, int32_t w,
+                             float* const dst[3], const int32_t c_begin[3], const int32_t c_count[3], void* stream);
+
 /*
  * `mask2color(seg)` (dnnlib/seg_tools.py:75-81: argmax over the class channel + palette) and
  * the uint8 conversion of `layout_grid` (dnnlib/util.py:632-646), fused: writes one

@@ -769,3 +769,74 @@ def test_triplane_image_groups_beyond_2gib(gpu_device):
         ref = fast_ops.sample_from_triplane(co[img:img + 1, idx].cpu(), planes[img:img + 1].cpu().contiguous())
         got = flat.reshape(n, -1, C)[img, idx]
         assert_close(got, ref, rtol=1e-5, atol=2e-5, what=f'image {img}')
+
+
+# ---- resampling between the big kernels (csrc/resample.hip) -----------------------------------------------------------
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 96, 32, 32), (1, 36, 13, 10), (3, 8, 5, 33)])
+def test_skip_upsample_add_channels_last(gpu_device, n, c, h, w):
+    """upsample2d(lo, [1,3,3,1]) + add written channels-last == the oracle's upsample2d + add (and == the NCHW HIP FIR path);
+    `add` is a channel slice of a wider tensor like the dual-head output; partial tiles and partial channel groups included."""
+    from torch_utils import hip_plugin
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(21)
+    lo = torch.randn(n, c, h, w, generator=g)
+    wide = torch.randn(n, 2 * c, 2 * h, 2 * w, generator=g)
+    add = wide[:, c:]
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    want = oracle_ops.upsample2d(lo.double(), f) + add.double()
+    before = _calls('skip_upsample_add_cl')
+    got = hip_plugin.ResamplePlugin.skip_upsample_add_cl(lo.to(gpu_device), wide.to(gpu_device)[:, c:])
+    assert _calls('skip_upsample_add_cl') == before + 1
+    assert got.shape == (n, c, 2 * h, 2 * w) and got.is_contiguous(memory_format=torch.channels_last)
+    assert_close(got, want, rtol=1e-6, atol=1e-6, what='skip accumulate (channels-last)')
+    nchw = upfirdn2d.upsample2d(lo.to(gpu_device), f.to(gpu_device)) + wide.to(gpu_device)[:, c:]
+    assert_close(got, nchw, rtol=1e-6, atol=1e-6, what='vs NCHW HIP path')
+
+
+def test_bilinear_up2_split(gpu_device):
+    """One-launch 2x bilinear (align_corners=False) split into (features, raw RGB, seg logits) == F.interpolate per slice."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(22)
+    for n, c, h, w, ranges in ((4, 51, 64, 64, [(0, 32), (0, 3), (32, 19)]), (2, 13, 7, 9, [(0, 8), (0, 3), (8, 5)]), (1, 5, 3, 4, [(1, 4)])):
+        x = torch.randn(n, c, h, w, generator=g)
+        outs = hip_plugin.ResamplePlugin.bilinear_up2_split(x.to(gpu_device), ranges)
+        assert len(outs) == len(ranges)
+        for o, (b, cnt) in zip(outs, ranges):
+            want = torch.nn.functional.interpolate(x[:, b:b + cnt], size=(2 * h, 2 * w), mode='bilinear', align_corners=False)
+            assert o.shape == want.shape
+            assert_close(o, want, rtol=1e-6, atol=1e-6, what=f'bilinear channels {b}+{cnt}')
+
+
+# ---- mapping network in one launch (csrc/mapping.hip) ---------------------------------------------------------------------
+
+def test_mapping_network_single_launch(golden, gpu_device):
+    """`MappingNetwork.forward` on the GPU = ONE launch of the fused kernel; equals the module's CPU definition (which is pinned
+    to the reference's MappingNetwork by tests/test_host_cpu.py) for full-size and tiny widths, with and without truncation."""
+    from training import networks
+    for (z_dim, c_dim, w_dim, num_ws, layers) in ((512, 25, 512, 18, 8), (32, 25, 32, 12, 2), (64, 0, 48, 5, 3)):
+        torch.manual_seed(3)
+        M = networks.MappingNetwork(z_dim, c_dim, w_dim, num_ws, num_layers=layers).eval()
+        with torch.no_grad():
+            M.w_avg.copy_(torch.randn(w_dim) * 0.3)
+        Mg = networks.MappingNetwork(z_dim, c_dim, w_dim, num_ws, num_layers=layers).eval()
+        Mg.load_state_dict(M.state_dict()); Mg = Mg.to(gpu_device)
+        g = torch.Generator().manual_seed(4)
+        for n in (1, 4, 7):
+            z = torch.randn(n, z_dim, generator=g); c = torch.randn(n, c_dim, generator=g) if c_dim else None
+            for psi, cutoff in ((1, None), (0.7, None), (0.3, 3)):
+                before = _calls('mapping')
+                with torch.no_grad():
+                    got = Mg(z.to(gpu_device), None if c is None else c.to(gpu_device), truncation_psi=psi, truncation_cutoff=cutoff)
+                    want = M(z, c, truncation_psi=psi, truncation_cutoff=cutoff)
+                assert _calls('mapping') == before + 1, 'the fused mapping kernel must have run'
+                assert got.shape == (n, num_ws, w_dim)
+                assert_close(got, want, rtol=1e-4, atol=1e-5, what=f'ws z{z_dim} n{n} psi{psi} cutoff{cutoff}')
+    # float64 latents (what the drivers feed: np.random.RandomState(seed).randn) and batches beyond the kernel's limit
+    z64 = torch.from_numpy(np.random.RandomState(0).randn(9, 64))
+    with torch.no_grad():
+        before = _calls('mapping')
+        got = Mg(z64.to(gpu_device), None)
+        assert _calls('mapping') == before, 'n = 9 > 8 takes the generic path'
+        assert_close(got, M(z64, None), rtol=1e-4, atol=1e-5, what='generic path')
+        assert_close(Mg(z64[:4].to(gpu_device), None), M(z64[:4], None), rtol=1e-4, atol=1e-5, what='float64 z')
