@@ -31,7 +31,7 @@ struct MapArgs {
     const float* fc_w[MAP_MAX_LAYERS]; const float* fc_b[MAP_MAX_LAYERS];
     int fc_in[MAP_MAX_LAYERS], fc_out[MAP_MAX_LAYERS];
     const float* w_avg;
-    float* act;                                             // [2][n][MAP_MAX_K] ping-pong
+    float* act;                                             // [layers][MAP_MAX_N][MAP_MAX_K]: one buffer per layer — an address is written once and read once per launch, so no stale L1 line can exist
     unsigned* counter;                                      // zeroed by the host before the launch
     float* ws;                                              // [n, num_ws, w_dim]
     int n, z_dim, c_dim, embed, layers, num_ws;
@@ -62,15 +62,24 @@ __device__ __forceinline__ void gemv_rows(const float* __restrict__ s_x, int n, 
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int m = 0; m < MAP_NB; ++m) acc[r][m] = 0.f;
-        for (int k = lane * 4; k < K; k += kWave * 4) {
-            float4 a[RB];
+        // all (row, 256-column slab) loads of this row group are requested before the first is used (K <= 1024: 4 slabs)
+        constexpr int NS = MAP_MAX_K / (kWave * 4);
+        float4 a[NS][RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(W + (int64_t)min(i0 + r, r1 - 1) * K + k);
+        for (int t = 0; t < NS; ++t) {
+            const int k = lane * 4 + t * kWave * 4;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                a[t][r] = (k < K) ? *reinterpret_cast<const float4*>(W + (int64_t)min(i0 + r, r1 - 1) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int k = min(lane * 4 + t * kWave * 4, K - 4);          // a[t] is zero beyond K
 #pragma unroll
             for (int m = 0; m < MAP_NB; ++m) {
                 const float4 xk = *reinterpret_cast<const float4*>(s_x + min(m0 + m, n - 1) * MAP_MAX_K + k);
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r][m] += (a[r].x * xk.x + a[r].y * xk.y) + (a[r].z * xk.z + a[r].w * xk.w);
+                for (int r = 0; r < RB; ++r) acc[r][m] += (a[t][r].x * xk.x + a[t][r].y * xk.y) + (a[t][r].z * xk.z + a[t][r].w * xk.w);
             }
         }
 #pragma unroll
@@ -129,11 +138,14 @@ mapping_kernel(const MapArgs p) {
     for (int l = 0; l < p.layers; ++l) {
         const int O = p.fc_out[l];
         const int per = cdiv(O, nwg), r0 = wg * per, r1 = min(O, r0 + per);
-        float* out = p.act + (size_t)(l & 1) * MAP_MAX_N * MAP_MAX_K;
+        float* out = p.act + (size_t)l * MAP_MAX_N * MAP_MAX_K;
         if (r0 < r1)
             gemv_rows<2>(s_x, p.n, K, p.fc_w[l], p.fc_b[l], r0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
         grid_barrier(p.counter, (unsigned)(l + 1) * nwg);
-        for (int i = tid; i < p.n * O; i += blockDim.x) { const int m = i / O, k = i - m * O; s_x[m * MAP_MAX_K + k] = __hip_atomic_load(&out[m * MAP_MAX_K + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // written by other CUs: not through this CU's L1
+        for (int i = tid * 4; i < p.n * O; i += blockDim.x * 4) {          // O % 4 == 0: 16-byte loads
+            const int m = i / O, k = i - m * O;
+            *reinterpret_cast<float4*>(s_x + m * MAP_MAX_K + k) = *reinterpret_cast<const float4*>(out + m * MAP_MAX_K + k);
+        }
         __syncthreads();
         K = O;
     }
@@ -157,7 +169,7 @@ mapping_kernel(const MapArgs p) {
 }  // namespace ide3d
 
 extern "C" int ide3d_mapping_workspace_bytes(void) {
-    return (int)(2 * ide3d::MAP_MAX_N * ide3d::MAP_MAX_K * sizeof(float) + 256);
+    return (int)(ide3d::MAP_MAX_LAYERS * ide3d::MAP_MAX_N * ide3d::MAP_MAX_K * sizeof(float) + 256);
 }
 
 extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
@@ -182,7 +194,7 @@ extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
     }
     a.w_avg = q->w_avg;
     a.act = reinterpret_cast<float*>(q->workspace);
-    a.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(q->workspace) + 2 * MAP_MAX_N * MAP_MAX_K * sizeof(float));
+    a.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(q->workspace) + (size_t)MAP_MAX_LAYERS * MAP_MAX_N * MAP_MAX_K * sizeof(float));
     a.ws = q->ws;
     a.n = q->n; a.z_dim = q->z_dim; a.c_dim = q->c_dim; a.embed = q->embed; a.layers = q->layers; a.num_ws = q->num_ws;
     a.embed_wgain = q->embed_weight_gain; a.embed_bgain = q->embed_bias_gain; a.lr_mul = q->lr_multiplier;

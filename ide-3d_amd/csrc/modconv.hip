@@ -599,6 +599,8 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout);
     if (allcls && pl.bm == 128 && mc_env().ta_rows == 64) pl.bm = 64;          // experiment: smaller M blocks (wave quantisation)
+    // 1x1 heads with cout = 192 (96 + 96 tri-plane channels): three 64-row blocks instead of 128 + 64 rows padded to 128
+    if (p.k == 1 && pl.bm == 128 && p.cout % 128 != 0 && p.cout % 64 == 0 && !getenv("IDE3D_MODCONV_HEAD_BM128")) pl.bm = 64;
     pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);

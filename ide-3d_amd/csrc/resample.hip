@@ -42,32 +42,51 @@ skip_upsample_add_cl_kernel(const SkipArgs p) {
     const int n = b;
     const int c0 = cg * SK_CH, Y0 = ty * SK_ROWS, X0 = tx * SK_COLS;
     const int H = 2 * p.h, W = 2 * p.w;
-    // ---- low-resolution patch (zero outside the image) ----
+    // ---- low-resolution patch (zero outside the image) and this thread's 32 `add` values: every global load of the tile is
+    // issued before the first one is used (one HBM round trip per workgroup instead of one per channel) ----
     const int m0 = Y0 / 2 - 1, q0 = X0 / 2 - 1;
-    for (int e = tid; e < SK_CH * SK_LR * SK_LC; e += 256) {
+    constexpr int NLO = (SK_CH * SK_LR * SK_LC + 255) / 256;
+    float lo_v[NLO];
+#pragma unroll
+    for (int i = 0; i < NLO; ++i) {
+        const int e = tid + i * 256;
         const int c = e / (SK_LR * SK_LC), r = e % (SK_LR * SK_LC), ry = r / SK_LC, rx = r % SK_LC;
         const int yy = m0 + ry, xx = q0 + rx;
-        float v = 0.f;
-        if (c0 + c < p.c && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
-            v = p.lo[n * p.lo_s[0] + (c0 + c) * p.lo_s[1] + yy * p.lo_s[2] + xx * p.lo_s[3]];
-        s_lo[c][ry][rx] = v;
+        const bool ok = e < SK_CH * SK_LR * SK_LC && c0 + c < p.c && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+        const int64_t off = n * p.lo_s[0] + (int64_t)min(c0 + c, p.c - 1) * p.lo_s[1] + (int64_t)min(max(yy, 0), p.h - 1) * p.lo_s[2]
+                          + (int64_t)min(max(xx, 0), p.w - 1) * p.lo_s[3];
+        const float v = p.lo[off];                       // unconditional load from a clamped address, masked afterwards
+        lo_v[i] = ok ? v : 0.f;
+    }
+    const int row = tid >> 5, x = tid & 31;
+    const int Y = Y0 + row, X = X0 + x;
+    const bool ok = Y < H && X < W;
+    float add_v[SK_CH];
+    {
+        const float* ap = p.add + n * p.add_s[0] + (int64_t)min(Y, H - 1) * p.add_s[2] + (int64_t)min(X, W - 1) * p.add_s[3];
+#pragma unroll
+        for (int c = 0; c < SK_CH; ++c) add_v[c] = ap[(int64_t)min(c0 + c, p.c - 1) * p.add_s[1]];
+    }
+#pragma unroll
+    for (int i = 0; i < NLO; ++i) {
+        const int e = tid + i * 256;
+        if (e < SK_CH * SK_LR * SK_LC) {
+            const int c = e / (SK_LR * SK_LC), r = e % (SK_LR * SK_LC);
+            s_lo[c][r / SK_LC][r % SK_LC] = lo_v[i];
+        }
     }
     __syncthreads();
     // ---- FIR + add in the NCHW thread layout (x fastest: 128-byte runs of `add`), result transposed into s_t ----
     {
-        const int row = tid >> 5, x = tid & 31;
-        const int Y = Y0 + row, X = X0 + x;
         // even output index 2m: (1 * in[m-1] + 3 * in[m]) / 4; odd 2m+1: (3 * in[m] + 1 * in[m+1]) / 4
         const int ly = (Y >> 1) - m0 - 1 + (Y & 1), lx = (X >> 1) - q0 - 1 + (X & 1);     // first of the two taps in the patch
         const float wy0 = (Y & 1) ? 0.75f : 0.25f, wy1 = 1.0f - wy0;
         const float wx0 = (X & 1) ? 0.75f : 0.25f, wx1 = 1.0f - wx0;
-        const bool ok = Y < H && X < W;
-        const float* ap = p.add + n * p.add_s[0] + (int64_t)Y * p.add_s[2] + (int64_t)X * p.add_s[3];
-#pragma unroll 4
+#pragma unroll
         for (int c = 0; c < SK_CH; ++c) {
             const float a = s_lo[c][ly][lx], bq = s_lo[c][ly][lx + 1], cq = s_lo[c][ly + 1][lx], d = s_lo[c][ly + 1][lx + 1];
             float v = wy0 * (wx0 * a + wx1 * bq) + wy1 * (wx0 * cq + wx1 * d);
-            if (ok && c0 + c < p.c) v += ap[(c0 + c) * p.add_s[1]];
+            if (ok && c0 + c < p.c) v += add_v[c];
             s_t[tid][c] = v;
         }
     }

@@ -100,6 +100,13 @@ def cases(device):
     out.append(('FIR 4x4 + noise/bias/lrelu 64ch 513->512', 'upfirdn2d_tile', 'hbm', (xi.numel() + N * 64 * 512 * 512) * 4,
                 lambda: upfirdn2d._plugin.upfirdn2d_ex(xi, f4, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0, noise=nz, noise_strength=1.0, bias=bb,
                                                        act=3, alpha=0.2, act_gain=math.sqrt(2), clamp=-1.0)))
+    # the last skip accumulation of the backbone, written channels-last (csrc/resample.hip): lo + add in, tri-plane out
+    lo_ = rn(N, 96, 128, 128); wide = rn(N, 192, 256, 256)
+    out.append(('skip upsample2d + add -> channels-last tri-plane 96ch 128->256', 'skip_upsample_add_cl', 'hbm', (lo_.numel() + 2 * N * 96 * 256 * 256) * 4,
+                lambda: hip_plugin.ResamplePlugin.skip_upsample_add_cl(lo_, wide[:, 96:])))
+    ft = rn(N, 51, 64, 64)
+    out.append(('bilinear 2x split [4,51,64,64] -> 32 + 3 + 19 ch @128', 'bilinear_up2_split', 'hbm', (ft.numel() + N * 54 * 128 * 128) * 4,
+                lambda: hip_plugin.ResamplePlugin.bilinear_up2_split(ft, [(0, 32), (0, 3), (32, 19)])))
     # generic kernel: separable 12-tap filter (training/augment.py:295 pattern), up = 2 -> two 1-D passes
     f12 = upfirdn2d.setup_filter([0.0154, 0.0035, -0.1180, -0.0483, 0.4911, 0.7877, 0.4911, -0.0483, -0.1180, 0.0035, 0.0154, 0.0],
                                  device=device, normalize=True)
