@@ -13,6 +13,7 @@
 // filtered_lrelu.py:215-216).  The intermediate (up^2 larger) never touches HBM: traffic = in + out
 // (+ signs).  Non-separable filters run the same passes with 2-D tap loops.
 #include "common.h"
+#include <stdlib.h>
 
 namespace ide3d {
 
@@ -225,6 +226,256 @@ filtered_lrelu_kernel(ide3d_filtered_lrelu_params p, FlrGeom g, int tiles_x, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Specialised kernel: separable filters, compile-time (up, down, taps) — the StyleGAN3 layer shapes
+// (filtered_lrelu.cu:1248-1278 instantiates 31 such variants; inversion/networks.py:576-597 picks 6 taps x up / down).
+// ------------------------------------------------------------------------------------------------
+// Same four LDS-resident passes as the generic kernel, but every inner loop is unrolled over compile-time taps / phases and
+// each thread owns a register micro-tile that shares its input window:
+//   P1 horizontal up-FIR   4 consecutive z columns of one input row   (window of 4 / UP + taps / UP inputs)
+//   P2 vertical up-FIR     one polyphase cell = UP z rows x 4 columns, + gain / lrelu / clamp / sign codes (16-byte LDS rows)
+//   P3 horizontal down-FIR 4 consecutive output columns of one z row  (window of 3 DOWN + taps values, 16-byte reads)
+//   P4 vertical down-FIR   2 output rows x 4 columns                   (window of DOWN + taps rows), 16-byte stores
+// 32 x 32 output tile: 44 KB of LDS at (up 2, down 2, 12 + 12 taps) -> three workgroups per CU instead of the generic kernel's
+// one, no integer division / modulo and no filter reads in the inner loops.  The op is VALU-bound, not HBM-bound:
+// ~92 multiply-adds per output element (6 + 6 up taps on a 4x larger intermediate, 12 + 12 down taps).
+template <int UP, int DOWN, int FUT, int FDT>
+struct FlsCfg {
+    static_assert(4 % UP == 0 && FUT % UP == 0, "up must divide 4 and the up filter length");
+    static constexpr int TOW = 32, TOH = 32;
+    static constexpr int NTU = FUT / UP;                                       // up taps per phase
+    static constexpr int ZW = (((TOW - 1) * DOWN + FDT) + 3) & ~3;             // activated intermediate tile
+    static constexpr int ZH = (TOH - 1) * DOWN + FDT;
+    static constexpr int IW = (ZW + 2 * UP - 2) / UP + NTU + 1;                // input tile (covers every phase offset)
+    static constexpr int IH = (ZH + 2 * UP - 2) / UP + NTU + 1;
+    static constexpr int N_IN = IW * IH, N_T = IH * ZW, N_Z = ZH * ZW, N_D = ZH * TOW;
+    static constexpr int OFF_T = (N_IN + 3) & ~3;
+    static constexpr int OFF_Z = (OFF_T + N_T + 3) & ~3;                       // s_d aliases s_in / s_t (dead once s_z is complete)
+    static constexpr int TOTAL = OFF_Z + N_Z;
+    static_assert(N_D <= OFF_Z, "the down-pass buffer must fit the space of the input and up-pass buffers");
+};
+
+template <class T, int UP, int DOWN, int FUT, int FDT, int SIGN>
+__global__ void __launch_bounds__(256)
+filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_y) {
+    using K = FlsCfg<UP, DOWN, FUT, FDT>;
+    __shared__ __attribute__((aligned(16))) float lds[K::TOTAL];
+    float* const s_in = lds;
+    float* const s_t = lds + K::OFF_T;
+    float* const s_z = lds + K::OFF_Z;
+    float* const s_d = lds;
+    const int tid = threadIdx.x;
+
+    // filters oriented for correlation (flipped unless p.flip), in registers (uniform loads)
+    float fu[FUT], fd[FDT];
+#pragma unroll
+    for (int i = 0; i < FUT; ++i) fu[i] = p.fu[(p.flip ? i : FUT - 1 - i) * p.fu_stride[1]];
+#pragma unroll
+    for (int i = 0; i < FDT; ++i) fd[i] = p.fd[(p.flip ? i : FDT - 1 - i) * p.fd_stride[1]];
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tix = bid % tiles_x; bid /= tiles_x;
+    const int tiy = bid % tiles_y; bid /= tiles_y;
+    const int plane = bid, n = plane / p.c, c = plane % p.c;
+    const int ox0 = tix * K::TOW, oy0 = tiy * K::TOH;
+    const int zx0 = ox0 * DOWN, zy0 = oy0 * DOWN;
+    const int ix0 = floordiv(zx0 - p.pad_x0, UP), iy0 = floordiv(zy0 - p.pad_y0, UP);
+    const int rx0 = (zx0 - p.pad_x0) - UP * ix0, ry0 = (zy0 - p.pad_y0) - UP * iy0;     // phase of local z index 0, in [0, UP)
+
+    // ---- P0: input + bias -> LDS (zero outside the image); all loads issued before the first LDS write ----
+    {
+        const T* xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
+        const float bias = Elem<T>::ld((const T*)p.b + c);
+        constexpr int NL = (K::N_IN + 255) / 256;
+        float v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + k * 256;
+            const int ly = i / K::IW, lx = i - ly * K::IW;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const int cy = min(max(iy, 0), p.in_h - 1), cx = min(max(ix, 0), p.in_w - 1);
+            const float t = Elem<T>::ld(xp + cy * p.x_stride[2] + cx * p.x_stride[3]);
+            v[k] = (iy == cy && ix == cx) ? t + bias : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const int i = tid + k * 256; if (i < K::N_IN) s_in[i] = v[k]; }
+    }
+    __syncthreads();
+
+    // ---- P1: horizontal up-FIR.  Thread item = (input row ly, group g): z columns j = 4 g - rx0 + e, e = 0..3, i.e. groups are
+    // aligned to the polyphase grid (s = rx0 + j = 4 g + e), so phase and tap set of e are compile-time:
+    //   first tap kx0 = (UP - e % UP) % UP, input column lx = ceil(s / UP) + t = 4 g / UP + ceil(e / UP) + t, taps kx0 + t UP.
+    {
+        constexpr int NG = (K::ZW + UP - 1 + 3) / 4 + 1;            // groups covering j = -rx0 .. ZW - 1
+        constexpr int WIN = 4 / UP + K::NTU;                        // distinct input columns a group touches (+1 when UP > 1)
+        for (int i = tid; i < K::IH * NG; i += 256) {
+            const int ly = i / NG, g = i - ly * NG;
+            const float* src = s_in + ly * K::IW + g * (4 / UP);
+            float w[WIN + 1];
+#pragma unroll
+            for (int k = 0; k < WIN + 1; ++k) w[k] = (g * (4 / UP) + k < K::IW) ? src[k] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                constexpr int dummy = 0; (void)dummy;
+                const int kx0 = (UP - e % UP) % UP, base = (e + UP - 1) / UP;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < K::NTU; ++t) acc += w[base + t] * fu[kx0 + t * UP];
+                const int j = 4 * g - rx0 + e;
+                if (j >= 0 && j < K::ZW) s_t[ly * K::ZW + j] = acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P2: vertical up-FIR + gain, lrelu, clamp (+ sign codes).  Thread item = (polyphase cell cy, column group x4): z rows
+    // jy = UP cy - ry0 + r, r = 0..UP-1, input rows ly = cy + ceil(r / UP) + t.
+    {
+        constexpr int NC = (K::ZH + UP - 1 + UP - 1) / UP + 1;       // cells covering jy = -ry0 .. ZH - 1
+        constexpr int ZW4 = K::ZW / 4;
+        const float zgain = (float)(UP * UP) * p.gain;
+        const int64_t s_plane = (int64_t)plane * p.s_h * p.s_w_bytes;
+        for (int i = tid; i < NC * ZW4; i += 256) {
+            const int cy = i / ZW4, x4 = (i - cy * ZW4) * 4;
+            float4 w[K::NTU + 1];
+#pragma unroll
+            for (int k = 0; k < K::NTU + 1; ++k)
+                w[k] = (cy + k < K::IH) ? *reinterpret_cast<const float4*>(s_t + (cy + k) * K::ZW + x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < UP; ++r) {
+                const int jy = UP * cy - ry0 + r;
+                if (jy < 0 || jy >= K::ZH) continue;
+                const int ky0 = (UP - r % UP) % UP, base = (r + UP - 1) / UP;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < K::NTU; ++t) {
+                    const float f = fu[ky0 + t * UP];
+                    v[0] += w[base + t].x * f; v[1] += w[base + t].y * f; v[2] += w[base + t].z * f; v[3] += w[base + t].w * f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= zgain;
+                const int signX = zx0 + x4 + p.s_ofs_x, signY = zy0 + jy + p.s_ofs_y;
+                if (SIGN == 1) {
+                    unsigned packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned code = __float_as_uint(v[j]) >> 31;
+                        if (code) v[j] *= p.slope;
+                        if (fabsf(v[j]) > p.clamp) { code = 2; v[j] = copysignf(p.clamp, v[j]); }
+                        packed |= code << (2 * j);
+                    }
+                    const int sb = signX >> 2;          // signX is a multiple of 4 (tile origin and s_ofs_x are)
+                    if (signX >= 0 && sb < p.sw_limit && signY >= 0 && signY < p.s_h)
+                        p.s[s_plane + (int64_t)signY * p.s_w_bytes + sb] = (uint8_t)packed;
+                } else if (SIGN == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int sx = signX + j;
+                        if (sx >= 0 && (sx >> 2) < p.sw_limit && (sx >> 2) < p.s_w_bytes && signY >= 0 && signY < p.s_h) {
+                            const unsigned code = (p.s[s_plane + (int64_t)signY * p.s_w_bytes + (sx >> 2)] >> ((sx & 3) << 1)) & 3u;
+                            if (code & 1u) v[j] *= p.slope;
+                            if (code & 2u) v[j] = 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (v[j] < 0.f) v[j] *= p.slope;
+                        v[j] = fminf(fmaxf(v[j], -p.clamp), p.clamp);
+                    }
+                }
+                *reinterpret_cast<float4*>(s_z + jy * K::ZW + x4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P3: horizontal down-FIR.  Thread item = (z row, 4 consecutive output columns): window of 3 DOWN + FDT values. ----
+    {
+        constexpr int WIN = 3 * DOWN + FDT, W4 = (WIN + 3) / 4;
+        for (int i = tid; i < K::ZH * (K::TOW / 4); i += 256) {
+            const int zy = i / (K::TOW / 4), o4 = (i - zy * (K::TOW / 4)) * 4;
+            const float* zr = s_z + zy * K::ZW + o4 * DOWN;
+            float w[W4 * 4];
+#pragma unroll
+            for (int k = 0; k < W4; ++k) {
+                const float4 q = (o4 * DOWN + 4 * k + 3 < K::ZW) ? *reinterpret_cast<const float4*>(zr + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+            }
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < FDT; ++k) acc[e] += w[e * DOWN + k] * fd[k];
+            *reinterpret_cast<float4*>(s_d + zy * K::TOW + o4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+
+    // ---- P4: vertical down-FIR -> global.  Thread item = (2 output rows, 4 columns): window of DOWN + FDT rows. ----
+    {
+        T* yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
+        constexpr int WIN = DOWN + FDT;
+        for (int i = tid; i < (K::TOH / 2) * (K::TOW / 4); i += 256) {
+            const int o2 = (i / (K::TOW / 4)) * 2, o4 = (i % (K::TOW / 4)) * 4;
+            float4 w[WIN];
+#pragma unroll
+            for (int k = 0; k < WIN; ++k)
+                w[k] = (o2 * DOWN + k < K::ZH) ? *reinterpret_cast<const float4*>(s_d + (o2 * DOWN + k) * K::TOW + o4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < FDT; ++k) {
+                    a[0] += w[e * DOWN + k].x * fd[k]; a[1] += w[e * DOWN + k].y * fd[k];
+                    a[2] += w[e * DOWN + k].z * fd[k]; a[3] += w[e * DOWN + k].w * fd[k];
+                }
+                const int oy = oy0 + o2 + e, ox = ox0 + o4;
+                if (oy >= p.out_h) continue;
+                T* yr = yp + oy * p.y_stride[2] + ox * p.y_stride[3];
+                if constexpr (sizeof(T) == 4) {
+                    if (ox + 3 < p.out_w && p.y_stride[3] == 1 && ((reinterpret_cast<uintptr_t>(yr) & 15) == 0)) {
+                        *reinterpret_cast<float4*>(yr) = make_float4(a[0], a[1], a[2], a[3]);
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (ox + j < p.out_w) Elem<T>::st(yr + j * p.y_stride[3], a[j]);
+            }
+        }
+    }
+}
+
+template <class T, int UP, int DOWN, int FUT, int FDT>
+static int launch_flr_sep(const ide3d_filtered_lrelu_params& p, hipStream_t st) {
+    using K = FlsCfg<UP, DOWN, FUT, FDT>;
+    const int tiles_x = cdiv(p.out_w, K::TOW), tiles_y = cdiv(p.out_h, K::TOH);
+    const int64_t nblocks = (int64_t)tiles_x * tiles_y * p.n * p.c;
+    if (nblocks > 0x7fffffff) { set_error("filtered_lrelu: grid too large"); return IDE3D_EINVAL; }
+    if (p.sign_mode == 1)      hipLaunchKernelGGL((filtered_lrelu_sep_kernel<T, UP, DOWN, FUT, FDT, 1>), dim3((unsigned)nblocks), dim3(256), 0, st, p, tiles_x, tiles_y);
+    else if (p.sign_mode == 2) hipLaunchKernelGGL((filtered_lrelu_sep_kernel<T, UP, DOWN, FUT, FDT, 2>), dim3((unsigned)nblocks), dim3(256), 0, st, p, tiles_x, tiles_y);
+    else                       hipLaunchKernelGGL((filtered_lrelu_sep_kernel<T, UP, DOWN, FUT, FDT, 0>), dim3((unsigned)nblocks), dim3(256), 0, st, p, tiles_x, tiles_y);
+    IDE3D_CHECK_LAUNCH("filtered_lrelu");
+    return IDE3D_OK;
+}
+
+// Returns 1 when a specialised instance ran, 0 when none matches (the generic kernel then takes the call), < 0 on error.
+template <class T>
+static int try_flr_sep(const ide3d_filtered_lrelu_params& p, hipStream_t st) {
+    static const bool off = getenv("IDE3D_FLR_GENERIC") != nullptr;
+    if (off || p.fu_h != 0 || p.fd_h != 0) return 0;                // separable filters only
+#define IDE3D_FLS(U, D, FU, FD) \
+    if (p.up == U && p.down == D && p.fu_w == FU && p.fd_w == FD) { const int rc = launch_flr_sep<T, U, D, FU, FD>(p, st); return rc ? rc : 1; }
+    IDE3D_FLS(2, 2, 12, 12)
+    IDE3D_FLS(4, 2, 12, 12)
+    IDE3D_FLS(4, 2, 24, 12)
+    IDE3D_FLS(2, 2, 8, 8)
+    IDE3D_FLS(2, 1, 12, 1)
+    IDE3D_FLS(1, 2, 1, 12)
+#undef IDE3D_FLS
+    return 0;
+}
+
 template <class T>
 static int launch_flr(const ide3d_filtered_lrelu_params& p, hipStream_t st) {
     FlrGeom g;
@@ -338,8 +589,8 @@ extern "C" int ide3d_filtered_lrelu(const ide3d_filtered_lrelu_params* pp, void*
     if (taps > 8192) { set_error("filtered_lrelu: filters too large for the fused kernel"); return IDE3D_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     switch (p.dtype) {
-    case IDE3D_F32:  return launch_flr<float>(p, st);
-    case IDE3D_F16:  return launch_flr<__half>(p, st);
+    case IDE3D_F32:  { const int r = try_flr_sep<float>(p, st); if (r) return r < 0 ? r : IDE3D_OK; return launch_flr<float>(p, st); }
+    case IDE3D_F16:  { const int r = try_flr_sep<__half>(p, st); if (r) return r < 0 ? r : IDE3D_OK; return launch_flr<__half>(p, st); }
     case IDE3D_BF16: return launch_flr<__hip_bfloat16>(p, st);
     }
     set_error("filtered_lrelu: no kernel for dtype code %d", p.dtype);
