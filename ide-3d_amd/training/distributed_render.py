@@ -76,7 +76,7 @@ def render_items(G, seeds: Sequence[int], yaws: Sequence[float], items: Sequence
                 ws_cache[s] = G.mapping(z, cond, truncation_psi=truncation_psi)
                 if cache_backbone:
                     voxel_ws, _ = G.synthesis.split_ws(ws_cache[s])
-                    plane_cache[s] = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode, force_fp32=True)
+                    plane_cache[s] = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode)
         ws = torch.cat([ws_cache[s] for s, _ in chunk])
         c = torch.cat([cams[p] for _, p in chunk])
         planes = None

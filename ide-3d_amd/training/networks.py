@@ -739,6 +739,13 @@ class SegSynthesisBlock(torch.nn.Module):
         w_iter = iter(ws.unbind(dim=1))
         dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
         memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        # fp16 blocks (reference :1058-1060: the high-resolution blocks of a released pickle store activations in fp16 with
+        # conv_clamp = 256) in MI355X inference: the HIP kernels compute in fp32 — exact products on the fp32 MFMA path, the same
+        # clamp fused in the epilogue — and the block's output activation is rounded to fp16 like the reference's storage format, so
+        # the tensors that cross block boundaries (and that viewer hooks see) have the reference's dtype at >= its precision.
+        out_dtype = dtype
+        if dtype == torch.float16 and ws.is_cuda and not torch.is_grad_enabled() and use_hip_modconv:
+            dtype, memory_format = torch.float32, torch.contiguous_format
         if fused_modconv is None:
             with misc.suppress_tracer_warnings():
                 fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
@@ -778,6 +785,8 @@ class SegSynthesisBlock(torch.nn.Module):
                 img = self._accumulate(img_lo, img, y)
                 seg = self._accumulate(seg_lo, seg, y_seg)
         assert x.dtype == dtype
+        if out_dtype != dtype:
+            x = x.to(out_dtype)
         assert img is None or img.dtype == torch.float32
         assert seg is None or seg.dtype == torch.float32
         return x, img, seg

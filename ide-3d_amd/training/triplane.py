@@ -63,6 +63,7 @@ class GeneratorSpec:
     ray_end: float = 3.3
     fov: float = 18.0
     conv_clamp: Optional[float] = None
+    num_fp16_res: int = 0             # StyleGAN2-style fp16 storage for the highest resolutions (0 = all fp32); implies conv_clamp 256
     clamp_mode: str = 'softplus'
     hierarchical: bool = False        # second, importance-sampled pass of `num_steps` more samples per ray
 
@@ -260,13 +261,17 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         self.block_resolutions = spec.sr_resolutions()
         plane_ch = 3 * spec.plane_channels
         layer_kwargs = dict(layer_name='training.networks.SynthesisLayer')
+        # fp16 blocks like the reference's SynthesisNetwork (inversion/networks.py:1168-1179: `use_fp16 = res >= fp16_resolution`,
+        # conv_clamp 256 with fp16): the top `num_fp16_res` resolutions of the voxel chain and, when any, the super-resolution blocks
+        conv_clamp = spec.conv_clamp if (spec.conv_clamp is not None or spec.num_fp16_res == 0) else 256
+        fp16_from = (spec.plane_resolution >> max(spec.num_fp16_res - 1, 0)) if spec.num_fp16_res > 0 else None
 
         self.num_ws = 0
         for res in self.voxel_block_resolutions:
             cin = spec.voxel_width(res // 2) if res > 4 else 0
             block = VoxelBlock(cin, spec.voxel_width(res), w_dim=spec.w_dim, resolution=res, img_channels=plane_ch,
-                               seg_channels=plane_ch, is_last=False, architecture='skip', conv_clamp=spec.conv_clamp,
-                               **layer_kwargs)
+                               seg_channels=plane_ch, is_last=False, architecture='skip', conv_clamp=conv_clamp,
+                               use_fp16=(fp16_from is not None and res >= max(fp16_from, 8)), **layer_kwargs)
             self.num_ws += block.num_conv
             setattr(self, f'vb{res}', block)
 
@@ -281,7 +286,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
             is_last = (res == self.img_resolution)
             block = networks.SegSynthesisBlock(cin, widths[res], w_dim=spec.w_dim, resolution=res,
                                                img_channels=spec.img_channels, seg_channels=spec.seg_channels,
-                                               is_last=is_last, architecture='skip', conv_clamp=spec.conv_clamp, **layer_kwargs)
+                                               is_last=is_last, architecture='skip', conv_clamp=conv_clamp,
+                                               use_fp16=(spec.num_fp16_res > 0), **layer_kwargs)
             self.num_ws += block.num_conv
             if is_last:
                 self.num_ws += block.num_torgb
@@ -335,7 +341,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         assert c is not None, 'synthesis needs the 25-D camera label c'
         render_params = dict(render_params or {})
         voxel_ws, block_ws = self.split_ws(ws)
-        block_kwargs = dict(noise_mode=noise_mode, force_fp32=True)
+        # `force_fp32` (viz/renderer.py:439 passes it) reaches the blocks; without fp16 blocks in the spec it changes nothing
+        block_kwargs = dict(noise_mode=noise_mode, force_fp32=force_fp32)
         # only while a hipGraph is being captured: with eager launches the host is the bottleneck and 43 extra events cost more
         # than the overlap returns (measured: -11 % on the eager video driver, +2.4 % on the graphed renderer)
         prefetch = (getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled()

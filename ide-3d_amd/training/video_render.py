@@ -85,7 +85,7 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
     planes = None
     if static:
         voxel_ws, _ = G.synthesis.split_ws(ws_frames[:, 0])
-        planes = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode, force_fp32=True)
+        planes = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode)
     palette = dr.palette_tensor(G.synthesis.seg_channels, device)
     for frame_idx in range(total):
         c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)

@@ -284,3 +284,39 @@ def test_hybrid_encoder_gpu(golden, gpu_device):
     assert _calls('modconv2d') - before == 2 * (1 + 3 * 6), 'every Conv2dLayer of both towers must run on the HIP conv kernel'
     ref = oenc.hybrid_encoder(sd, img, seg, 10, 8, 512, ops=fast_ops)
     _rel(got, ref, 1e-3, 'hybrid encoder 256 vs oracle')
+
+
+def test_fp16_blocks_fp32_compute(gpu_device):
+    """A spec with StyleGAN2-style fp16 blocks (`num_fp16_res`, conv_clamp 256 — what a released pickle carries,
+    inversion/networks.py:1058-1060,1168-1179): the block outputs that cross block boundaries are fp16 (viewer hooks see the
+    reference's dtypes), the HIP kernels compute in fp32, the images stay within fp16 storage error of the all-fp32 generator, and
+    `force_fp32=True` (viz/renderer.py:439) reproduces the all-fp32 generator bit for bit."""
+    from training import triplane
+    torch.manual_seed(0)
+    spec32 = triplane.tiny_spec(conv_clamp=256)
+    spec16 = triplane.tiny_spec(num_fp16_res=2)
+    G32 = triplane.TriPlaneGenerator(spec32).eval()
+    G16 = triplane.TriPlaneGenerator(spec16).eval()
+    G16.load_state_dict(G32.state_dict())
+    assert [b.use_fp16 for b in (G16.synthesis.vb8, G16.synthesis.vb16, G16.synthesis.vb32, G16.synthesis.b32, G16.synthesis.b64)] == [False, True, True, True, True]
+    assert G16.synthesis.vb32.conv1.conv_clamp == 256
+    G32, G16 = G32.to(gpu_device), G16.to(gpu_device)
+    z = torch.from_numpy(np.random.RandomState(1).randn(2, G32.z_dim)).to(gpu_device)
+    c = torch.cat([triplane.camera_label(0.2), triplane.camera_label(-0.4)]).to(gpu_device)
+    cond = triplane.conditioning_label(gpu_device).repeat(2, 1)
+    seen = {}
+    hooks = [blk.register_forward_hook(lambda m, i, o, n=name: seen.__setitem__(n, o[0].dtype))
+             for name, blk in (('vb8', G16.synthesis.vb8), ('vb32', G16.synthesis.vb32), ('b64', G16.synthesis.b64))]
+    before = _calls('modconv2d')
+    with torch.no_grad():
+        ws = G32.mapping(z, cond)
+        img32, seg32 = G32.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True)
+        img16, seg16 = G16.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True)
+        img16f, seg16f = G16.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True, force_fp32=True)
+    for h in hooks:
+        h.remove()
+    assert _calls('modconv2d') - before == 3 * 16, 'every convolution of the fp16 blocks must stay on the HIP kernel (16 launches per pass)'
+    assert seen == {'vb8': torch.float32, 'vb32': torch.float16, 'b64': torch.float16}
+    assert img16.dtype == torch.float32 and seg16.dtype == torch.float32
+    assert torch.equal(img16f, img32) and torch.equal(seg16f, seg32)
+    _rel(img16, img32, 5e-3, 'image with fp16 block storage'); _rel(seg16, seg32, 5e-3, 'seg with fp16 block storage')
