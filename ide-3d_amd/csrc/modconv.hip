@@ -598,7 +598,13 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout);
-    if (allcls && pl.bm == 128 && mc_env().ta_rows == 64) pl.bm = 64;          // experiment: smaller M blocks (wave quantisation)
+    if (allcls && pl.bm == 128) {
+        // all-class transposed conv with too few 128-row blocks to fill the 768 resident slots (3 per CU): 64-row blocks double
+        // the block count (512 -> 512 in@32: 432 -> 864 blocks, measured +5 %)
+        const int64_t blocks128 = (int64_t)cdiv(p.cout, 128) * cdiv(p.h + 1, 4) * cdiv(p.w_ + 1, 16) * p.n;
+        static const bool old_plan = getenv("IDE3D_MODCONV_TA_OLD") != nullptr;
+        if ((blocks128 < 3 * kNumCU * 3 / 4 && !old_plan) || mc_env().ta_rows == 64 || getenv("IDE3D_MODCONV_TA_BM64")) pl.bm = 64;
+    }
     // 1x1 heads with cout = 192 (96 + 96 tri-plane channels): three 64-row blocks instead of 128 + 64 rows padded to 128
     if (p.k == 1 && pl.bm == 128 && p.cout % 128 != 0 && p.cout % 64 == 0 && !getenv("IDE3D_MODCONV_HEAD_BM128")) pl.bm = 64;
     pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
@@ -631,7 +637,11 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         // (~11 B/clk/CU) is what bounds the small tile — 8 x 16 / 16 x 16 positions with 16 accumulators per wave (AGPRs, one
         // workgroup per CU): twice the MFMAs per streamed weight byte
         pl.tile = 4;
+        // 64-row blocks have registers for 8 x 16 positions (8 accumulators per wave): half the weight bytes streamed per MFMA
+        // (128 -> 64 in@256: measured +3.5 %) as long as enough blocks remain
+        if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n >= 4 * kNumCU && !getenv("IDE3D_MODCONV_TA_OLD")) pl.tile = 6;
         const int rows = mc_env().ta_rows ? mc_env().ta_rows : 0;
+        if (rows == 4) pl.tile = 4;
         if (rows == 8 && pl.big == 1) pl.tile = 6;
         if (rows == 16 && pl.big == 2) pl.tile = 7;
         if (rows == 8 && pl.big == 2) pl.tile = 6;
