@@ -60,14 +60,14 @@ template <> struct ModeCfg<MODE_TCONV3> { static constexpr int KC = 4, WTAPS = 9
 // patch and all 9 taps (each tap feeds exactly one class), i.e. 4x the MFMA work per staging step / barrier of mode 2.
 template <> struct ModeCfg<MODE_TCONV3A> { static constexpr int KC = 4, WTAPS = 9, MAXT = 9; };
 
-template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4>
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4, int KCO = 0>      // KCO: input channels per K chunk (0 = the mode's default)
 struct McCfg {
     static constexpr int NT = 64 * NWV;                     // threads per workgroup (4 or 8 waves)
     static constexpr int BN = TI * PH * PW;
     static_assert(BN == 64 || BN == 128 || BN == 256, "pixel tile must hold 64, 128 or 256 pixels");
     static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;   // accumulator sets (output parity classes)
     using MC = ModeCfg<MODE>;
-    static constexpr int KC = MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
+    static constexpr int KC = KCO ? KCO : MC::KC, WTAPS = MC::WTAPS, MAXT = MC::MAXT;
     // BIG: 1 -> BM 128 (waves 2 x 2, two M tiles each); 2 -> BM 64 (waves 2 x 2, one M tile each); 0 -> BM 32 (waves 1 x 4)
     static constexpr int WM = BIG ? 2 : 1, WN = NWV / WM;
     static constexpr int MTW = (BIG == 1) ? 2 : 1;          // 32-row M tiles per wave
@@ -167,11 +167,11 @@ __host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3
 
 // One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
 // (MODE_TCONV3 only).  s_w / s_x: two buffers of K::LDS_W / K::LDS_X floats.
-template <int MODE, int BIG, int TI, int PH, int PW, int NWV>
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV, int KCO>
 __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, const float* __restrict__ wp, float* __restrict__ partial,
                                              const ConvGeom& g, float* s_w, float* s_x, int mb, int tl, int grp, int split, int cls,
                                              int tiles_x) {
-    using K = McCfg<MODE, BIG, TI, PH, PW, NWV>;
+    using K = McCfg<MODE, BIG, TI, PH, PW, NWV, KCO>;
 #ifdef IDE3D_MC_TRACE
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
@@ -523,21 +523,21 @@ __device__ __forceinline__ BlockId decode_block(const ConvGeom& g) {
     return b;
 }
 
-template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4>
+template <int MODE, int BIG, int TI, int PH, int PW, int NWV = 4, int KCO = 0>
 // 4-wave workgroups: 128-pixel (and smaller) tiles need <= 168 VGPRs and <= 53 KB of LDS, three workgroups per CU (measured +2 %
 // frames/s over two); the stride-2 mode's (2P + 1) x (2Q + 1) patches need more LDS than that; 16 accumulators per wave take
 // AGPRs and one workgroup per CU.  8-wave workgroups: one per CU, two waves per SIMD.
 __global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 2
-                                  : (McCfg<MODE, BIG, TI, PH, PW, NWV>::NCLS * McCfg<MODE, BIG, TI, PH, PW, NWV>::MTW * McCfg<MODE, BIG, TI, PH, PW, NWV>::NTW > 8) ? 1
-                                  : (TI * PH * PW <= 128 && MODE != MODE_CONV3S2) ? 3 : 2)
+                                  : (McCfg<MODE, BIG, TI, PH, PW, NWV, KCO>::NCLS * McCfg<MODE, BIG, TI, PH, PW, NWV, KCO>::MTW * McCfg<MODE, BIG, TI, PH, PW, NWV, KCO>::NTW > 8) ? 1
+                                  : (TI * PH * PW <= 128 && MODE != MODE_CONV3S2 && KCO == 0) ? 3 : 2)
 modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
-    using K = McCfg<MODE, BIG, TI, PH, PW, NWV>;
+    using K = McCfg<MODE, BIG, TI, PH, PW, NWV, KCO>;
     __shared__ __attribute__((aligned(16))) float s_w[2 * K::LDS_W];
     __shared__ __attribute__((aligned(16))) float s_x[2 * K::LDS_X];
     const BlockId b = decode_block(g);
     int cls = 0;
     if (MODE == MODE_TCONV3) { cls = (b.tile >= g.tile_base[1]) + (b.tile >= g.tile_base[2]) + (b.tile >= g.tile_base[3]); }
-    modconv_tile<MODE, BIG, TI, PH, PW, NWV>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
+    modconv_tile<MODE, BIG, TI, PH, PW, NWV, KCO>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
 }
 
 // reduce split-K partials + epilogue
@@ -607,8 +607,12 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     }
     // 1x1 heads with cout = 192 (96 + 96 tri-plane channels): three 64-row blocks instead of 128 + 64 rows padded to 128
     if (p.k == 1 && pl.bm == 128 && p.cout % 128 != 0 && p.cout % 64 == 0 && !getenv("IDE3D_MODCONV_HEAD_BM128")) pl.bm = 64;
+    // experiment (IDE3D_MODCONV_TA_KC8): all-class transposed conv as 64-row blocks x 8 x 16 positions x 8 input channels per chunk:
+    // 72 MFMAs per wave and barrier instead of 36, 18 KB of weights streamed per 72 MFMAs instead of per 36
+    bool ta_kc8 = false;
+    if (allcls && p.cin % 8 == 0 && getenv("IDE3D_MODCONV_TA_KC8")) { pl.bm = 64; ta_kc8 = true; }
     pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
-    pl.kc = mc_kc(p.k); pl.taps = p.k * p.k;
+    pl.kc = ta_kc8 ? 8 : mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
     const bool transposed = (pl.mode == MODE_TCONV3 || pl.mode == MODE_TCONV3A);
     pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
@@ -642,6 +646,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n >= 4 * kNumCU && !getenv("IDE3D_MODCONV_TA_OLD")) pl.tile = 6;
         const int rows = mc_env().ta_rows ? mc_env().ta_rows : 0;
         if (rows == 4) pl.tile = 4;
+        if (ta_kc8) pl.tile = 11;
         if (rows == 8 && pl.big == 1) pl.tile = 6;
         if (rows == 16 && pl.big == 2) pl.tile = 7;
         if (rows == 8 && pl.big == 2) pl.tile = 6;
@@ -649,7 +654,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (rows == 108) pl.tile = (pl.big == 1) ? 8 : 9;
     }
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
-    static const int TIv[10] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1}, PHv[10] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16}, PWv[10] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16};
+    static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -678,7 +683,8 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     if constexpr (MODE == MODE_TCONV3A) {
         if constexpr (BIG != 0) {
-            if (pl.tile == 8) { if constexpr (BIG == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16, 8>), dim3(nblocks), dim3(512), 0, st, p, wp, partial, g); }
+            if (pl.tile == 11) { if constexpr (BIG == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16, 4, 8>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g); }
+            else if (pl.tile == 8) { if constexpr (BIG == 1) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16, 8>), dim3(nblocks), dim3(512), 0, st, p, wp, partial, g); }
             else if (pl.tile == 9) { if constexpr (BIG == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16, 8>), dim3(nblocks), dim3(512), 0, st, p, wp, partial, g); }
             else if (pl.tile == 6) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 8, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
             else if (pl.tile == 7) { if constexpr (BIG == 2) hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g); }
