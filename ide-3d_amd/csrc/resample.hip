@@ -119,26 +119,35 @@ struct BilinArgs {
 
 __global__ void __launch_bounds__(256)
 bilinear_up2_split_kernel(const BilinArgs p) {
-    const int H = 2 * p.h, W = 2 * p.w;
+    // a thread produces 4 consecutive output pixels of one row (w % 2 == 0 checked on the host, so 2w % 4 == 0): they need input
+    // columns x0 - 1 .. x0 + 2 of two input rows; one 16-byte store
+    const int H = 2 * p.h, W = 2 * p.w, W4 = W / 4;
     const int ctot = p.c_count[0] + p.c_count[1] + p.c_count[2];
-    const int64_t total = (int64_t)p.n * ctot * H * W;
+    const int64_t total = (int64_t)p.n * ctot * H * W4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int64_t r = i;
-        const int X = (int)(r % W); r /= W;
+        const int X = (int)(r % W4) * 4; r /= W4;
         const int Y = (int)(r % H); r /= H;
         int cc = (int)(r % ctot);
         const int n = (int)(r / ctot);
         int k = 0;
         if (cc >= p.c_count[0]) { cc -= p.c_count[0]; k = 1; if (cc >= p.c_count[1]) { cc -= p.c_count[1]; k = 2; } }
         const int ci = p.c_begin[k] + cc;
-        const float sy = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)X + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < p.h - 1), x1 = x0 + (x0 < p.w - 1);
-        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-        const float* src = p.x + ((int64_t)n * p.c + ci) * ((int64_t)p.h * p.w);
-        const float v = ly0 * (lx0 * src[y0 * p.w + x0] + lx1 * src[y0 * p.w + x1]) + ly1 * (lx0 * src[y1 * p.w + x0] + lx1 * src[y1 * p.w + x1]);
-        p.dst[k][(((int64_t)n * p.c_count[k] + cc) * H + Y) * W + X] = v;
+        const float sy = fmaxf(0.5f * ((float)Y + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, y1 = y0 + (y0 < p.h - 1);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = p.x + ((int64_t)n * p.c + ci) * ((int64_t)p.h * p.w) + (int64_t)y0 * p.w;
+        const float* r1 = r0 + (int64_t)(y1 - y0) * p.w;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sx = fmaxf(0.5f * ((float)(X + e) + 0.5f) - 0.5f, 0.f);
+            const int x0 = (int)sx, x1 = x0 + (x0 < p.w - 1);
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            o[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        }
+        *reinterpret_cast<float4*>(p.dst[k] + (((int64_t)n * p.c_count[k] + cc) * H + Y) * W + X) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -168,6 +177,7 @@ extern "C" int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, in
     using namespace ide3d;
     IDE3D_CHECK_ARG(x && dst && c_begin && c_count, "bilinear_up2_split: null pointer");
     IDE3D_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0, "bilinear_up2_split: bad shape");
+    IDE3D_CHECK_ARG(w % 2 == 0, "bilinear_up2_split: input width must be even (16-byte output stores)");
     BilinArgs a;
     a.x = x; a.n = n; a.c = c; a.h = h; a.w = w;
     int64_t total = 0;
@@ -175,7 +185,8 @@ extern "C" int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, in
         a.dst[k] = dst[k]; a.c_begin[k] = c_begin[k]; a.c_count[k] = c_count[k];
         IDE3D_CHECK_ARG(c_count[k] >= 0 && c_begin[k] >= 0 && c_begin[k] + c_count[k] <= c && (c_count[k] == 0 || dst[k]),
                         "bilinear_up2_split: channel range %d outside the input", k);
-        total += (int64_t)n * c_count[k] * 4 * h * w;
+        IDE3D_CHECK_ARG(c_count[k] == 0 || (reinterpret_cast<uintptr_t>(dst[k]) & 15) == 0, "bilinear_up2_split: output %d is not 16-byte aligned", k);
+        total += (int64_t)n * c_count[k] * 2 * h * (w / 2);
     }
     if (total == 0) return IDE3D_OK;
     hipLaunchKernelGGL(bilinear_up2_split_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a);

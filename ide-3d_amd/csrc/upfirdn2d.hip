@@ -334,6 +334,20 @@ static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilo
             if (p.up_x == 1 && p.up_y == 1 && p.down_x == 2 && p.down_y == 2)
                 return launch_tile<T, 1, 1, 2, 2, 4, 4, 4, 2>(p, ep, st);
         }
+        // one pass of a separable 12-tap filter (upfirdn2d.py:192-199 runs [1, 12] then [12, 1]; training/augment.py:295,306 sym6
+        // wavelets, StyleGAN3-style up / down by 2): the same LDS-tiled polyphase kernel with a 1-D tap set
+        if constexpr (std::is_same<T, float>::value) {
+            if (w_contig && p.f_w == 12 && p.f_h == 1 && p.up_y == 1 && p.down_y == 1) {
+                if (p.up_x == 2 && p.down_x == 1) return launch_tile<T, 2, 1, 1, 1, 12, 1, 2, 4>(p, ep, st);
+                if (p.up_x == 1 && p.down_x == 2) return launch_tile<T, 1, 1, 2, 1, 12, 1, 4, 4>(p, ep, st);
+                if (p.up_x == 1 && p.down_x == 1) return launch_tile<T, 1, 1, 1, 1, 12, 1, 4, 4>(p, ep, st);
+            }
+            if (w_contig && p.f_w == 1 && p.f_h == 12 && p.up_x == 1 && p.down_x == 1) {
+                if (p.up_y == 2 && p.down_y == 1) return launch_tile<T, 1, 2, 1, 1, 1, 12, 4, 2>(p, ep, st);
+                if (p.up_y == 1 && p.down_y == 2) return launch_tile<T, 1, 1, 1, 2, 1, 12, 4, 2>(p, ep, st);
+                if (p.up_y == 1 && p.down_y == 1) return launch_tile<T, 1, 1, 1, 1, 1, 12, 4, 4>(p, ep, st);
+            }
+        }
     }
     return launch_generic<T>(p, ep, st);
 }

@@ -322,7 +322,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         """[N, feat+seg, R, R] composited features -> (img, seg) at full resolution."""
         fc = self.spec.feature_channels
         size = self.block_resolutions[0] // 2
-        if (size == 2 * feat.shape[-1] and size == 2 * feat.shape[-2] and networks._inference_on_gpu(feat) and networks._resample_init()):
+        if (size == 2 * feat.shape[-1] and size == 2 * feat.shape[-2] and feat.shape[-1] % 2 == 0 and networks._inference_on_gpu(feat)
+                and networks._resample_init()):
             # one launch (csrc/resample.hip) instead of three ATen bilinear launches: same source-index rule and weights
             x, img, seg = networks._resample_plugin.bilinear_up2_split(
                 feat, [(0, fc), (0, self.img_channels), (fc, feat.shape[1] - fc)])

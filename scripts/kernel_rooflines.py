@@ -113,7 +113,7 @@ def cases(device):
     xs = rn(N, 64, 128, 128)
     ys = upfirdn2d.upsample2d(xs, f12, up=2)
     mid = N * 64 * 128 * 256        # elements after the first (horizontal) pass
-    out.append(('FIR generic sym-12 separable up2 64ch 128->256 (2 passes)', 'upfirdn2d_generic', 'hbm',
+    out.append(('FIR 12-tap separable up2 64ch 128->256 (two 1-D tile passes)', 'upfirdn2d_generic', 'hbm',
                 (xs.numel() + 2 * mid + ys.numel()) * 4, lambda: upfirdn2d.upsample2d(xs, f12, up=2)))
     f47 = upfirdn2d.setup_filter(np.outer(np.hanning(47), np.hanning(47)), device=device)
     xv = rn(1, 3, 128, 128)
