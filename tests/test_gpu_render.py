@@ -312,9 +312,9 @@ def test_fp16_blocks_fp32_compute(gpu_device):
         ws = G32.mapping(z, cond)
         img32, seg32 = G32.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True)
         img16, seg16 = G16.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True)
+        for h in hooks:                  # the forced-fp32 pass below would overwrite the recorded dtypes
+            h.remove()
         img16f, seg16f = G16.synthesis(ws, c=c, noise_mode='const', ray_jitter=False, return_seg=True, force_fp32=True)
-    for h in hooks:
-        h.remove()
     assert _calls('modconv2d') - before == 3 * 17, 'every convolution of the fp16 blocks must stay on the HIP kernel (17 launches per pass)'
     assert seen == {'vb8': torch.float32, 'vb32': torch.float16, 'b64': torch.float16}
     assert img16.dtype == torch.float32 and seg16.dtype == torch.float32
