@@ -32,6 +32,7 @@
 // Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace ide3d {
@@ -164,6 +165,122 @@ __host__ __device__ constexpr int tap_patch_offset(int t) {
 }
 template <int MODE>
 __host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3A) ? ((t / 3) & 1) * 2 + ((t % 3) & 1) : 0; }
+
+// ---- epilogue (shared by the fp32-MFMA and the split-bf16 main loops) ------------------------------------------------
+// acc[class][m tile][n tile] in the 32x32 MFMA C layout; `lp` = the pixel (0..31, in tile order) that this lane's MFMA column
+// holds inside each 32-pixel N tile (the lane's own index for the fp32 path; a permutation for the split-bf16 path).
+// `s_w`: LDS scratch of SCRATCH floats that the main loop has finished with (the caller's last barrier covers it).
+template <int MODE, int TI, int PH, int PW, int NWV, int NCLS, int MTW, int NTW, int BM, int SCRATCH>
+__device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, float* __restrict__ partial, const ConvGeom& g,
+                                               f32x16 (&acc)[NCLS][MTW][NTW], float* s_w, int mb, int n0, int y0, int x0, int split, int cls,
+                                               int wm, int wn, int lp) {
+    constexpr int NT = 64 * NWV;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int cpy = cls >> 1, cpx = cls & 1;
+    const bool raw = (g.split_k > 1);
+    // Demodulation coefficients and biases of this block's BM output channels go to LDS first (the K loop has finished with
+    // s_w): a lane's 16 x MTW accumulator rows are 16 x MTW different channels, and one global load per row in front of each
+    // store exposes its latency that many times (measured: the epilogue took as long as 7 - 60 K chunks).
+    float* const s_dm = s_w;                       // [TI][BM]
+    float* const s_bi = s_w + TI * BM;          // [BM]
+    for (int e = tid; e < TI * BM; e += NT) {
+        const int rl = e % BM, co = mb * BM + rl, n = min(n0 + e / BM, p.n - 1);
+        s_dm[e] = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
+        if (e < BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
+    }
+    __syncthreads();
+    float* const dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
+    // Branch-free finish: absent terms are identities (d = 1, b = 0 in LDS; slope 1 = linear; clamp +inf; split-K partials
+    // take all of them), so the 128 values of a lane do not cost four uniform branches each.
+    const float e_alpha = (!raw && p.act == 3) ? p.alpha : 1.f, e_gain = raw ? 1.f : p.gain;
+    const float e_clamp = (!raw && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+    const float e_nstr = (!raw && p.noise) ? p.noise_strength : 0.f;
+    auto finish = [&](float v, float d, float nz, float bb) {
+        v *= d; v += nz; v += bb;
+        v = (v > 0.f) ? v : v * e_alpha;
+        v *= e_gain;
+        return fminf(fmaxf(v, -e_clamp), e_clamp);
+    };
+    // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores and 16 different
+    // demodulation / bias values.  RR channel rows of raw accumulators go through a wave-private LDS tile ([row][pixel], the
+    // two x-parity classes of the all-class transposed convolution interleaved); a lane then takes 4 consecutive output
+    // pixels of ONE channel, finishes them (one d / b pair, one 16-byte noise load) and stores 16 bytes.
+    constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = NCLS / QX;
+    constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
+    constexpr int AVAIL = SCRATCH - (TI + 1) * BM;
+    constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= NWV * 32 * TP) ? 32 : (AVAIL >= NWV * 16 * TP) ? 16 : (AVAIL >= NWV * 8 * TP) ? 8 : 0;
+    if constexpr (RR > 0) {
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        float* const T = s_w + (TI + 1) * BM + wid * (RR * TP);
+#pragma unroll
+        for (int qy = 0; qy < QY; ++qy)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int pbase = (wn * NTW + j) * 32;
+            // what a lane stores depends on (row, pixel group); the pixel group c4 = lane % (TW / 4) is the same in every round
+            const int c4 = lane % (TW / 4), row0 = lane / (TW / 4);
+            const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
+            const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
+            const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
+            const bool px_ok = n < p.n && oy < g.oh && ox < g.ow, full = ox + 3 < g.ow;
+            const int64_t pofs = (int64_t)oy * g.ow + ox;
+            f32x4u nz = {0.f, 0.f, 0.f, 0.f};
+            if (e_nstr != 0.f && px_ok) {
+                if (full) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
+                else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[pofs + e] * e_nstr;
+            }
+            float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * g.ow) + pofs;
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int g0 = 0; g0 < 4; g0 += RR / 8) {
+#pragma unroll
+                for (int qx = 0; qx < QX; ++qx)
+#pragma unroll
+                    for (int gg = 0; gg < RR / 8; ++gg)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            T[(gg * 8 + rr + 4 * half) * TP + lp * QX + qx] = acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr];
+#pragma unroll
+                for (int k = 0; k < RR * (TW / 4) / 64; ++k) {
+                    const int rowl = row0 + k * (256 / TW);
+                    f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
+                    const int rl = (wm * MTW + i) * 32 + g0 * 8 + rowl, co = mb * BM + rl;
+                    if (!px_ok || co >= p.cout) continue;
+                    const float d = s_dm[ti * BM + rl], bb = s_bi[rl];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
+                    float* o = o_px + (int64_t)co * ((int64_t)g.oh * g.ow);
+                    if (full) *reinterpret_cast<f32x4u*>(o) = v4;
+                    else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int pix = (wn * NTW + j) * 32 + lp;
+        const int ti = pix / (PH * PW), rem = pix % (PH * PW);
+        const int n = n0 + ti;
+        const int gy = y0 + rem / PW, gx = x0 + rem % PW;              // (class-)grid coordinates
+        const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy, ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
+        const bool ok = n < p.n && oy < g.oh && ox < g.ow;
+        if (!ok) continue;
+        const float nz = (e_nstr != 0.f) ? p.noise[oy * g.ow + ox] * e_nstr : 0.f;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
+                const int co = mb * BM + rl;
+                if (co >= p.cout) continue;
+                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = finish(acc[q][i][j][r], s_dm[ti * BM + rl], nz, s_bi[rl]);
+            }
+    }
+    }
+}
 
 // One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
 // (MODE_TCONV3 only).  s_w / s_x: two buffers of K::LDS_W / K::LDS_X floats.
@@ -397,110 +514,7 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
 #ifdef IDE3D_MC_TRACE
     const unsigned long long mc_t1 = __builtin_readcyclecounter();
 #endif
-    // ---- epilogue ----
-    const bool raw = (g.split_k > 1);
-    // Demodulation coefficients and biases of this block's BM output channels go to LDS first (the K loop has finished with
-    // s_w): a lane's 16 x MTW accumulator rows are 16 x MTW different channels, and one global load per row in front of each
-    // store exposes its latency that many times (measured: the epilogue took as long as 7 - 60 K chunks).
-    float* const s_dm = s_w;                       // [TI][BM]
-    float* const s_bi = s_w + TI * K::BM;          // [BM]
-    for (int e = tid; e < TI * K::BM; e += K::NT) {
-        const int rl = e % K::BM, co = mb * K::BM + rl, n = min(n0 + e / K::BM, p.n - 1);
-        s_dm[e] = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
-        if (e < K::BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
-    }
-    __syncthreads();
-    float* const dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
-    // Branch-free finish: absent terms are identities (d = 1, b = 0 in LDS; slope 1 = linear; clamp +inf; split-K partials
-    // take all of them), so the 128 values of a lane do not cost four uniform branches each.
-    const float e_alpha = (!raw && p.act == 3) ? p.alpha : 1.f, e_gain = raw ? 1.f : p.gain;
-    const float e_clamp = (!raw && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
-    const float e_nstr = (!raw && p.noise) ? p.noise_strength : 0.f;
-    auto finish = [&](float v, float d, float nz, float bb) {
-        v *= d; v += nz; v += bb;
-        v = (v > 0.f) ? v : v * e_alpha;
-        v *= e_gain;
-        return fminf(fmaxf(v, -e_clamp), e_clamp);
-    };
-    // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores and 16 different
-    // demodulation / bias values.  RR channel rows of raw accumulators go through a wave-private LDS tile ([row][pixel], the
-    // two x-parity classes of the all-class transposed convolution interleaved); a lane then takes 4 consecutive output
-    // pixels of ONE channel, finishes them (one d / b pair, one 16-byte noise load) and stores 16 bytes.
-    constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = K::NCLS / QX;
-    constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
-    constexpr int AVAIL = 2 * K::LDS_W - (TI + 1) * K::BM;
-    constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= NWV * 32 * TP) ? 32 : (AVAIL >= NWV * 16 * TP) ? 16 : (AVAIL >= NWV * 8 * TP) ? 8 : 0;
-    if constexpr (RR > 0) {
-        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-        float* const T = s_w + (TI + 1) * K::BM + wid * (RR * TP);
-#pragma unroll
-        for (int qy = 0; qy < QY; ++qy)
-#pragma unroll
-        for (int j = 0; j < K::NTW; ++j) {
-            const int pbase = (wn * K::NTW + j) * 32;
-            // what a lane stores depends on (row, pixel group); the pixel group c4 = lane % (TW / 4) is the same in every round
-            const int c4 = lane % (TW / 4), row0 = lane / (TW / 4);
-            const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
-            const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
-            const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
-            const bool px_ok = n < p.n && oy < g.oh && ox < g.ow, full = ox + 3 < g.ow;
-            const int64_t pofs = (int64_t)oy * g.ow + ox;
-            f32x4u nz = {0.f, 0.f, 0.f, 0.f};
-            if (e_nstr != 0.f && px_ok) {
-                if (full) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
-                else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[pofs + e] * e_nstr;
-            }
-            float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * g.ow) + pofs;
-#pragma unroll
-            for (int i = 0; i < K::MTW; ++i)
-#pragma unroll
-            for (int g0 = 0; g0 < 4; g0 += RR / 8) {
-#pragma unroll
-                for (int qx = 0; qx < QX; ++qx)
-#pragma unroll
-                    for (int gg = 0; gg < RR / 8; ++gg)
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr)
-                            T[(gg * 8 + rr + 4 * half) * TP + l32 * QX + qx] = acc[qy * QX + qx][i][j][(g0 + gg) * 4 + rr];
-#pragma unroll
-                for (int k = 0; k < RR * (TW / 4) / 64; ++k) {
-                    const int rowl = row0 + k * (256 / TW);
-                    f32x4u v4 = *reinterpret_cast<const f32x4u*>(T + rowl * TP + c4 * 4);
-                    const int rl = (wm * K::MTW + i) * 32 + g0 * 8 + rowl, co = mb * K::BM + rl;
-                    if (!px_ok || co >= p.cout) continue;
-                    const float d = s_dm[ti * K::BM + rl], bb = s_bi[rl];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
-                    float* o = o_px + (int64_t)co * ((int64_t)g.oh * g.ow);
-                    if (full) *reinterpret_cast<f32x4u*>(o) = v4;
-                    else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e];
-                }
-            }
-        }
-    } else {
-#pragma unroll
-    for (int q = 0; q < K::NCLS; ++q)
-#pragma unroll
-    for (int j = 0; j < K::NTW; ++j) {
-        const int pix = (wn * K::NTW + j) * 32 + l32;
-        const int ti = pix / (PH * PW), rem = pix % (PH * PW);
-        const int n = n0 + ti;
-        const int gy = y0 + rem / PW, gx = x0 + rem % PW;              // (class-)grid coordinates
-        const int oy = (MODE == MODE_TCONV3) ? 2 * gy + cpy : gy, ox = (MODE == MODE_TCONV3) ? 2 * gx + cpx : gx;
-        const bool ok = n < p.n && oy < g.oh && ox < g.ow;
-        if (!ok) continue;
-        const float nz = (e_nstr != 0.f) ? p.noise[oy * g.ow + ox] * e_nstr : 0.f;
-#pragma unroll
-        for (int i = 0; i < K::MTW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * K::MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
-                const int co = mb * K::BM + rl;
-                if (co >= p.cout) continue;
-                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = finish(acc[q][i][j][r], s_dm[ti * K::BM + rl], nz, s_bi[rl]);
-            }
-    }
-    }
+    modconv_finish<MODE, TI, PH, PW, NWV, K::NCLS, K::MTW, K::NTW, K::BM, 2 * K::LDS_W>(p, partial, g, acc, s_w, mb, n0, y0, x0, split, cls, wm, wn, l32);
 #ifdef IDE3D_MC_TRACE
     if (blockIdx.x == 100 && threadIdx.x == 0) {
         for (int k = 0; k < 6; ++k) g_mc_dbg[k] = mc_acc[k];
@@ -509,6 +523,268 @@ __device__ __forceinline__ void modconv_tile(const ide3d_modconv_params& p, cons
         g_mc_dbg[9] = __builtin_readcyclecounter() - mc_t1;      // epilogue: issue of the stores (not their completion)
     }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// split-bf16 main loop (3x3 and all-class transposed 3x3, 8x16 / 16x16 / 4x16 pixel tiles)
+// ------------------------------------------------------------------------------------------------
+// fp32 has no fast matrix path on gfx950 (v_mfma_f32_32x32x2_f32 runs at the vector rate, 1/16 of the bf16 rate), so the
+// big 3x3 layers can instead split every fp32 operand into PARTS bf16 pieces (a = a0 + a1 [+ a2], round-to-nearest at each
+// step, residuals exact in fp32) and sum the products a_i * b_j with i + j < PARTS on v_mfma_f32_32x32x16_bf16 (bf16 products
+// are exact in fp32; accumulation is fp32 like the fp32 MFMA's):
+//   PARTS = 3: 6 products, dropped terms <= 2^-24 relative (a1 b2 + a2 b1 + ...): fp32-grade products at 6 / 16 of the fp32 MFMA time;
+//   PARTS = 2: 3 products, dropped terms ~ 2^-17 relative: 3 / 16 of the time.
+// Layout differences from the fp32 loop:
+//   * K chunk = 16 input channels = one MFMA K; a lane holds 8 consecutive channels of one pixel / output channel (16 bytes,
+//     `ds_read_b128`).  LDS images in 16-byte units: weights [tap][part][k half][co], patch [part][k half][y][x];
+//   * weights are staged per (chunk, kernel row) - 3 taps, 96 x PARTS x BM bytes - by LDS-DMA from the pre-split packed copy;
+//     the patch is staged once per chunk: wave q loads channel quad q of every patch pixel (its 4 styles are wave-uniform),
+//     scales, splits and writes 8 bytes per part;
+//   * an MFMA N tile is 2 pixel rows x 16: lane l takes x = l % 16 and row = bit2 ^ bit3 ^ bit4 of l, so that each of the four
+//     16-lane groups a `ds_read_b128` is serviced in ({0-3,12-15,20-27}, ...) reads one contiguous 256-byte row segment:
+//     conflict-free for every tap shift and any row pitch.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MODE, int BIG, int PH, int PARTS>
+struct SpCfg {
+    static_assert(MODE == MODE_CONV3 || MODE == MODE_TCONV3A, "split-bf16 loop: 3x3 and all-class transposed 3x3 only");
+    static_assert(BIG == 1 || BIG == 2, "64- or 128-row blocks");
+    static constexpr int PW = 16, NT = 256, NWV = 4;
+    static constexpr int BN = PH * PW;
+    static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;
+    static constexpr int WM = 2, WN = 2;
+    static constexpr int MTW = (BIG == 1) ? 2 : 1, NTW = BN / 64;
+    static_assert(NTW >= 1, "at least 64 pixels");
+    static constexpr int BM = 64 * MTW;
+    static constexpr int KC = 16;
+    static constexpr int HP = PH + 2, HW = PW + 2, NSLOT = HP * HW;
+    static constexpr int NS = PARTS * (PARTS + 1) / 2;               // products per k step
+    static constexpr int W_UNITS = 3 * PARTS * 2 * BM;               // 16-byte units per weight stage (one kernel row)
+    static constexpr int X_UNITS = PARTS * 2 * NSLOT;                // per patch buffer
+    static constexpr int NXR = (NSLOT + 63) / 64;                    // patch pixels per lane
+    static constexpr int LDS_BYTES = 2 * 16 * (W_UNITS + X_UNITS);
+};
+
+__host__ __device__ inline int64_t sp_packed_units(int mblocks, int cchunks, int bm, int parts) { return (int64_t)mblocks * cchunks * 9 * parts * 2 * bm; }
+
+// round-to-nearest-even bf16 pair (v_cvt_pk_bf16_f32): low half = a, high half = b
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// a, b -> PARTS packed bf16 pairs whose sums reproduce a and b (residuals are exact in fp32)
+template <int PARTS>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PARTS]) {
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) {
+        const unsigned pk = pk_bf16(a, b);
+        out[q] = pk;
+        if (q + 1 < PARTS) { a -= __uint_as_float(pk << 16); b -= __uint_as_float(pk & 0xffff0000u); }
+    }
+}
+
+// weights w [cout, cin, 3, 3] -> [mb][chunk][ky][kx][part][k half][co][8 channels] bf16 (zero padded)
+template <int PARTS>
+__global__ void __launch_bounds__(256)
+modconv_pack_split_kernel(const float* __restrict__ w, int cout, int cin, int bm, int mblocks, int cchunks, u32x4* __restrict__ out) {
+    const int64_t total = (int64_t)mblocks * cchunks * 9 * 2 * bm;   // one thread per (mb, chunk, tap, k half, co): all parts
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int64_t r = i;
+        const int co_l = (int)(r % bm); r /= bm;
+        const int kg = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int cc = (int)(r % cchunks); r /= cchunks;
+        const int mb = (int)r;
+        const int co = mb * bm + co_l;
+        unsigned pk[4][PARTS];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = cc * 16 + kg * 8 + e * 2;
+            const float a = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 9 + tap] : 0.f;
+            const float b = (co < cout && ci + 1 < cin) ? w[((int64_t)co * cin + ci + 1) * 9 + tap] : 0.f;
+            split_pair<PARTS>(a, b, pk[e]);
+        }
+        const int64_t base = (((int64_t)(mb * cchunks + cc) * 9 + tap) * PARTS * 2 + kg) * bm + co_l;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) {
+            const u32x4 v = {pk[0][q], pk[1][q], pk[2][q], pk[3][q]};
+            out[base + (int64_t)q * 2 * bm] = v;
+        }
+    }
+}
+
+template <int OFF_BYTES>
+__device__ __forceinline__ u32x4 lds_read128_async(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait128(u32x4& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
+__device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)); }
+
+template <int MODE, int BIG, int PH, int PARTS>
+__device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
+                                                   const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x) {
+    using K = SpCfg<MODE, BIG, PH, PARTS>;
+    constexpr int PW = K::PW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / K::WN, wn = wid % K::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int lp = ((((l32 >> 2) ^ (l32 >> 3) ^ (l32 >> 4)) & 1) << 4) | (l32 & 15);     // pixel of this lane inside an N tile
+    const int txi = tl % tiles_x, tyi = tl / tiles_x;
+    const int y0 = tyi * PH, x0 = txi * PW;
+    const int n0 = grp;                                                                 // one image per tile
+    u32x4* const s_w = reinterpret_cast<u32x4*>(smem);                                  // [2][W_UNITS]
+    u32x4* const s_x = s_w + 2 * K::W_UNITS;                                            // [2][X_UNITS]
+
+    f32x16 acc[K::NCLS][K::MTW][K::NTW];
+#pragma unroll
+    for (int q = 0; q < K::NCLS; ++q)
+#pragma unroll
+        for (int i = 0; i < K::MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < K::NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+
+    // ---- patch staging plan: wave `wid` owns channel quad `wid` of the chunk; lane -> patch pixels lane + 64 r ----
+    const int hw = p.h * p.w_;
+    int x_src[K::NXR];                       // offset of the pixel inside a channel plane, -1 = outside the image / the patch
+#pragma unroll
+    for (int r = 0; r < K::NXR; ++r) {
+        const int sidx = lane + 64 * r;
+        const int ry = sidx / K::HW, rx = sidx % K::HW;
+        const int yy = y0 - 1 + ry, xx = x0 - 1 + rx;
+        x_src[r] = (sidx < K::NSLOT && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_) ? yy * p.w_ + xx : -1;
+    }
+    const float* __restrict__ ximg = p.x + (int64_t)n0 * p.cin * hw;
+    float xreg[K::NXR][4];
+    float sty[4];
+    auto fetch_patch = [&](int c) {
+        const int ci0 = c * K::KC + wid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = min(ci0 + k, p.cin - 1);
+            sty[k] = (ci0 + k < p.cin) ? (p.styles ? p.styles[(int64_t)n0 * p.cin + ci] : 1.f) : 0.f;
+#pragma unroll
+            for (int r = 0; r < K::NXR; ++r) xreg[r][k] = ximg[(int64_t)ci * hw + max(x_src[r], 0)];
+        }
+    };
+    auto commit_patch = [&](int buf) {
+        unsigned char* const dst = reinterpret_cast<unsigned char*>(s_x + buf * K::X_UNITS) + ((wid >> 1) * K::NSLOT) * 16 + (wid & 1) * 8;
+#pragma unroll
+        for (int r = 0; r < K::NXR; ++r) {
+            const int sidx = lane + 64 * r;
+            const bool live = x_src[r] >= 0;
+            unsigned lo[PARTS], hi[PARTS];
+            split_pair<PARTS>(live ? xreg[r][0] * sty[0] : 0.f, live ? xreg[r][1] * sty[1] : 0.f, lo);
+            split_pair<PARTS>(live ? xreg[r][2] * sty[2] : 0.f, live ? xreg[r][3] * sty[3] : 0.f, hi);
+            if (sidx < K::NSLOT) {
+#pragma unroll
+                for (int q = 0; q < PARTS; ++q) {
+                    const u32x2 v = {lo[q], hi[q]};
+                    *reinterpret_cast<u32x2*>(dst + (q * 2 * K::NSLOT + sidx) * 16) = v;
+                }
+            }
+        }
+    };
+    // ---- weight stage (chunk c, kernel row ky): one contiguous slab, already the LDS image ----
+    const u32x4* __restrict__ wsrc = wp + (int64_t)mb * g.cchunks * 3 * K::W_UNITS;
+    constexpr int W_PIECES = K::W_UNITS / 64;                        // 1 KB pieces (64 lanes x 16 bytes)
+    static_assert(K::W_UNITS % 64 == 0, "weight stage is a whole number of 1 KB pieces");
+    auto fetch_weights = [&](int stage, int buf) {
+        const u32x4* src = wsrc + (int64_t)stage * K::W_UNITS;
+        for (int i = wid; i < W_PIECES; i += K::NWV)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(s_w + buf * K::W_UNITS + i * 64), 16, 0, 0);
+    };
+
+    // ---- operand addresses ----
+    const unsigned a_base0 = (unsigned)(size_t)(s_w + half * K::BM + wm * K::MTW * 32 + l32);
+    unsigned b_base0[K::NTW];
+#pragma unroll
+    for (int j = 0; j < K::NTW; ++j) {
+        const int pix = (wn * K::NTW + j) * 32 + lp;
+        b_base0[j] = (unsigned)(size_t)(s_x + half * K::NSLOT + (pix / PW) * K::HW + (pix % PW));
+    }
+
+    const int c_begin = split * g.chunks_per_split;
+    const int c_end = min(c_begin + g.chunks_per_split, g.cchunks);
+    if (c_begin < c_end) {
+        fetch_weights(c_begin * 3, 0);
+        fetch_patch(c_begin);
+        commit_patch(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int wbuf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int xbuf = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        static_for<3>([&](auto kyy) {
+            constexpr int KY = decltype(kyy)::value;
+            if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1);
+            if (KY == 1 && more) fetch_patch(c + 1);
+            // ---- MFMAs of kernel row KY: taps pipelined (operands of tap kx + 1 in flight while tap kx multiplies) ----
+            const unsigned a_base = a_base0 + wbuf * (K::W_UNITS * 16);
+            unsigned b_base[K::NTW];
+#pragma unroll
+            for (int j = 0; j < K::NTW; ++j) b_base[j] = b_base0[j] + xbuf * (K::X_UNITS * 16);
+            u32x4 av[2][K::MTW][PARTS], bv[2][K::NTW][PARTS];
+            constexpr int NRD = (K::MTW + K::NTW) * PARTS;
+            auto issue = [&](auto kxx) {
+                constexpr int KX = decltype(kxx)::value, B = KX & 1, T = KY * 3 + KX;
+                static_for<PARTS>([&](auto qq) {
+                    constexpr int Q = decltype(qq)::value;
+                    static_for<K::MTW>([&](auto ii) {
+                        constexpr int I = decltype(ii)::value;
+                        av[B][I][Q] = lds_read128_async<(((KX * PARTS + Q) * 2) * K::BM + I * 32) * 16>(a_base);
+                    });
+                    static_for<K::NTW>([&](auto jj) {
+                        constexpr int J = decltype(jj)::value;
+                        bv[B][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
+                    });
+                });
+            };
+            issue(std::integral_constant<int, 0>{});
+            static_for<3>([&](auto kxx) {
+                constexpr int KX = decltype(kxx)::value, B = KX & 1, QC = tap_class<MODE>(KY * 3 + KX);
+                if constexpr (KX + 1 < 3) issue(std::integral_constant<int, KX + 1>{});
+                lds_wait128<(KX + 1 < 3) ? (NRD < 15 ? NRD : 15) : 0>(av[B][0][0]);
+#pragma unroll
+                for (int q = 0; q < PARTS; ++q) {
+#pragma unroll
+                    for (int i = 0; i < K::MTW; ++i) lds_pin128(av[B][i][q]);
+#pragma unroll
+                    for (int j = 0; j < K::NTW; ++j) lds_pin128(bv[B][j][q]);
+                }
+                // products a_qa * b_qb with qa + qb < PARTS, smallest terms first
+#pragma unroll
+                for (int sum = PARTS - 1; sum >= 0; --sum)
+#pragma unroll
+                    for (int qa = 0; qa <= sum; ++qa)
+#pragma unroll
+                        for (int i = 0; i < K::MTW; ++i)
+#pragma unroll
+                            for (int j = 0; j < K::NTW; ++j)
+                                acc[QC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[B][i][qa]),
+                                                                                        __builtin_bit_cast(bf16x8, bv[B][j][sum - qa]), acc[QC][i][j], 0, 0, 0);
+            });
+            if (KY == 2 && more) commit_patch(xbuf ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            wbuf ^= 1;
+        });
+    }
+    modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp);
 }
 
 // ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
@@ -540,6 +816,16 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
     modconv_tile<MODE, BIG, TI, PH, PW, NWV, KCO>(p, wp, partial, g, s_w, s_x, b.mb, b.tile - g.tile_base[cls], b.grp, b.split, cls, g.tiles_x[cls]);
 }
 
+
+template <int MODE, int BIG, int PH, int PARTS>
+__global__ void __launch_bounds__(256, (SpCfg<MODE, BIG, PH, PARTS>::LDS_BYTES <= 80 * 1024 && SpCfg<MODE, BIG, PH, PARTS>::NCLS * SpCfg<MODE, BIG, PH, PARTS>::MTW * SpCfg<MODE, BIG, PH, PARTS>::NTW <= 8) ? 2 : 1)
+modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
+    using K = SpCfg<MODE, BIG, PH, PARTS>;
+    __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
+    const BlockId b = decode_block(g);
+    modconv_split_tile<MODE, BIG, PH, PARTS>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
+}
+
 // reduce split-K partials + epilogue
 __global__ void __launch_bounds__(256)
 modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partial, int split_k, int oh, int ow) {
@@ -568,6 +854,7 @@ modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partia
 struct ConvPlan {
     int mode, big, tile;             // tile: 0 = 1x8x16, 1 = 2x8x8, 2 = 8x4x4
     int bm, kc, taps, mblocks, cchunks, oh, ow;
+    int parts;                       // 0: fp32 MFMA loop; 2 / 3: split-bf16 loop with that many pieces per operand
     int64_t packed_floats, partial_floats;
     ConvGeom g;
 };
@@ -593,7 +880,23 @@ static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
     return p;
 }
 
-static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
+// Arithmetic of the big 3x3 layers: 1 = fp32 MFMA (exact fp32 products), 6 = three bf16 pieces per operand / 6 products
+// (fp32-grade), 3 = two pieces / 3 products (~2^-17 relative per product).  Process default: IDE3D_CONV_ARITH, else fp32.
+static int g_conv_arith = 0;
+static int conv_arith_default() {
+    if (g_conv_arith) return g_conv_arith;
+    static const int env = [] {
+        const char* e = getenv("IDE3D_CONV_ARITH");
+        if (!e) return 1;
+        if (!strcmp(e, "bf16x3") || !strcmp(e, "3")) return 3;
+        if (!strcmp(e, "bf16x6") || !strcmp(e, "6")) return 6;
+        return 1;
+    }();
+    return env;
+}
+static int resolve_arith(int a) { return (a == 1 || a == 3 || a == 6) ? a : conv_arith_default(); }
+
+static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
@@ -618,6 +921,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
     pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
     pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
+    pl.parts = 0;
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -654,6 +958,23 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl) {
         if (rows == 108) pl.tile = (pl.big == 1) ? 8 : 9;
     }
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
+    // split-bf16 loop: shared-weight 3x3 / all-class transposed layers on 16-pixel-wide tiles, 64- or 128-row blocks
+    if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 &&
+        (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8) {
+        pl.parts = (arith == 3) ? 2 : 3;
+        static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
+        if (pl.mode == MODE_CONV3) {
+            if (sp_rows == 8) pl.tile = 0;
+            if (sp_rows == 16) pl.tile = 3;
+        } else {
+            if (pl.big == 1 && pl.tile == 7) pl.tile = 6;            // 128-row blocks: at most 8 x 16 positions (16 accumulators)
+            if (sp_rows == 4) pl.tile = 4;
+            if (sp_rows == 8) pl.tile = 6;
+            if (sp_rows == 16 && pl.big == 2) pl.tile = 7;
+        }
+        pl.kc = 16; pl.cchunks = cdiv(p.cin, 16);
+        pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
+    }
     static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
@@ -702,6 +1023,17 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
         hipLaunchKernelGGL((modconv_kernel<MODE, BIG, 1, 16, 16>), dim3(nblocks), dim3(256), 0, st, p, wp, partial, g);
 }
 
+
+template <int MODE, int BIG, int PARTS>
+static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
+    const ConvGeom& g = pl.g;
+    const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
+    const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
+    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g); }
+    else if (pl.tile == 0 || pl.tile == 6) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+    else if constexpr (MODE == MODE_CONV3 || BIG == 2) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+}
+
 }  // namespace ide3d
 
 static int check_modconv(const ide3d_modconv_params& p) {
@@ -722,10 +1054,17 @@ extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t
     p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w; p.k = k; p.mode = mode; p.w_batch_stride = per_image_weights ? 1 : 0;
     if (check_modconv(p) != IDE3D_OK) return -1;
     p.x = nullptr;                               // alignment of the real tensor is unknown here: size for the larger plan
-    ConvPlan pl; plan_conv(p, pl);
-    ConvPlan pf; plan_conv(flatten_pointwise(p), pf);
-    if (pf.partial_floats > pl.partial_floats) pl.partial_floats = pf.partial_floats;
-    return (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float);
+    // sized for every arithmetic (the packed copy of the split-bf16 loops is the larger one) and for the flattened 1x1 plan
+    int64_t packed = 0, part = 0;
+    for (int arith : {1, 3, 6}) {
+        ConvPlan pl; plan_conv(p, pl, arith);
+        ConvPlan pf; plan_conv(flatten_pointwise(p), pf, arith);
+        for (const ConvPlan* q : {&pl, &pf}) {
+            if (q->packed_floats > packed) packed = q->packed_floats;
+            if (q->partial_floats > part) part = q->partial_floats;
+        }
+    }
+    return (packed + part) * (int64_t)sizeof(float);
 }
 
 extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
@@ -736,12 +1075,24 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     int rc = check_modconv(p);
     if (rc) return rc;
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
-    ConvPlan pl; plan_conv(p, pl);
+    ConvPlan pl; plan_conv(p, pl, resolve_arith(p.arith));
     IDE3D_CHECK_ARG(p.workspace_bytes >= (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float),
                     "modconv2d: workspace too small (need %lld bytes)", (long long)((pl.packed_floats + pl.partial_floats) * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
     float* wp = p.workspace;
     float* partial = p.workspace + pl.packed_floats;
+    if (pl.parts) {
+        if (!p.weights_packed) {
+            const int64_t items = (int64_t)pl.mblocks * pl.cchunks * 9 * 2 * pl.bm;
+            if (pl.parts == 2) hipLaunchKernelGGL(modconv_pack_split_kernel<2>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp));
+            else               hipLaunchKernelGGL(modconv_pack_split_kernel<3>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp));
+        }
+#define IDE3D_SP_DISPATCH(M) \
+        do { if (pl.big == 1) { if (pl.parts == 2) launch_split<M, 1, 2>(p, pl, wp, partial, st); else launch_split<M, 1, 3>(p, pl, wp, partial, st); } \
+             else             { if (pl.parts == 2) launch_split<M, 2, 2>(p, pl, wp, partial, st); else launch_split<M, 2, 3>(p, pl, wp, partial, st); } } while (0)
+        if (pl.mode == MODE_CONV3) IDE3D_SP_DISPATCH(MODE_CONV3); else IDE3D_SP_DISPATCH(MODE_TCONV3A);
+#undef IDE3D_SP_DISPATCH
+    } else {
     if (!p.weights_packed) {
         hipLaunchKernelGGL(modconv_pack_kernel, dim3(stream_grid(pl.packed_floats, 256)), dim3(256), 0, st,
                            p.w, p.w_batch_stride, p.w_batch_stride ? p.n : 1, p.cout, p.cin, pl.taps, pl.bm, pl.kc, pl.mblocks, pl.cchunks, wp);
@@ -755,6 +1106,7 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     else if (pl.mode == MODE_TCONV3A) IDE3D_MC_DISPATCH(MODE_TCONV3A);
     else                             IDE3D_MC_DISPATCH(MODE_TCONV3);
 #undef IDE3D_MC_DISPATCH
+    }
     if (pl.g.split_k > 1) {
         const int64_t per = (int64_t)p.n * p.cout * pl.oh * pl.ow;
         hipLaunchKernelGGL(modconv_epilogue_kernel, dim3(stream_grid(per, 256)), dim3(256), 0, st, p, partial, pl.g.split_k, pl.oh, pl.ow);
@@ -762,6 +1114,13 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     IDE3D_CHECK_LAUNCH("modconv2d");
     return IDE3D_OK;
 }
+
+extern "C" int ide3d_set_conv_arithmetic(int32_t arith) {
+    IDE3D_CHECK_ARG(arith == 0 || arith == 1 || arith == 3 || arith == 6, "set_conv_arithmetic: 0 (environment default), 1 (fp32), 3 (bf16x3) or 6 (bf16x6)");
+    ide3d::g_conv_arith = arith;
+    return IDE3D_OK;
+}
+extern "C" int32_t ide3d_get_conv_arithmetic(void) { return ide3d::conv_arith_default(); }
 
 #ifdef IDE3D_MC_TRACE
 extern "C" int ide3d_debug_mc(unsigned long long* host) {

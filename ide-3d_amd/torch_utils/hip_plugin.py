@@ -115,7 +115,7 @@ class _ModconvParams(ctypes.Structure):
         ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
         ('mode', ctypes.c_int32), ('weights_packed', ctypes.c_int32),
         ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
-        ('w_batch_stride', ctypes.c_int64),
+        ('w_batch_stride', ctypes.c_int64), ('arith', ctypes.c_int32),
     ]
 
 
@@ -197,6 +197,8 @@ def load():
             'ide3d_density_lattice': [ctypes.POINTER(_RenderParams), ctypes.POINTER(_Lattice), i64, i64, vp, vp],
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
             'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32, i32],
+            'ide3d_set_conv_arithmetic': [i32],
+            'ide3d_get_conv_arithmetic': [],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
             'ide3d_style_demod': [vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp],
             'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
@@ -218,7 +220,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
-    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
+    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes',
 )
 
@@ -693,8 +695,9 @@ class ModconvPlugin:
     _ws = {}
 
     @staticmethod
-    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0):
-        """mode 0: stride-1 k x k (modulated) conv, "same" padding, fused epilogue; mode 1: 3x3 stride-2 conv without padding
+    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0, arith=0):
+        """arith: 0 = process default (`conv_arithmetic`), 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (include/ide3d_hip.h).
+        mode 0: stride-1 k x k (modulated) conv, "same" padding, fused epilogue; mode 1: 3x3 stride-2 conv without padding
         (output ((h-3)//2+1) x ((w-3)//2+1)); mode 2: 3x3 transposed stride-2 conv (output (2h+1) x (2w+1)).
         styles / dcoefs / noise / bias may be None."""
         for t in (x, w):
@@ -713,8 +716,10 @@ class ModconvPlugin:
         lib = load()
         # one workspace per (weight, problem shape, device, stream): the split-K partials inside it belong to one launch at a
         # time, and launches on different streams (a graph replay next to an eager call) must not share them
+        # ... and per arithmetic: the packed weights of the split-bf16 loops differ from the fp32 loop's
+        arith = int(arith) or int(lib.ide3d_get_conv_arithmetic())
         key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index,
-               torch.cuda.current_stream(x.device).cuda_stream)
+               torch.cuda.current_stream(x.device).cuda_stream, arith)
         ent = ModconvPlugin._ws.get(key)
         if ent is None:
             nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode, int(per_image))
@@ -743,12 +748,28 @@ class ModconvPlugin:
         # can be recycled by the allocator for another weight of the same shape
         p.weights_packed = int((not per_image) and ent[2] is not None and ent[2]() is w and ent[1] == w._version)
         p.w_batch_stride = (cout * cin * k * k) if per_image else 0
+        p.arith = arith
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         with torch.cuda.device(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
         ent[1], ent[2] = (None, None) if per_image else (w._version, weakref.ref(w))
         return y
+
+
+_ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'default': 0}
+
+
+def conv_arithmetic(name=None):
+    """Get (no argument) or set the process-wide arithmetic of the shared-weight 3x3 convolutions: 'fp32' (exact fp32 products on
+    the fp32 MFMA), 'bf16x6' (3 bf16 pieces per operand, 6 products: fp32-grade), 'bf16x3' (2 pieces, 3 products, ~2^-17 per
+    product) or 'default' (back to the IDE3D_CONV_ARITH environment default).  Returns the name in force."""
+    lib = load()
+    if name is not None:
+        _require(name in _ARITH_NAMES, f'conv_arithmetic: one of {sorted(_ARITH_NAMES)}')
+        _check(lib.ide3d_set_conv_arithmetic(_ARITH_NAMES[name]), 'set_conv_arithmetic')
+    code = int(lib.ide3d_get_conv_arithmetic())
+    return {1: 'fp32', 3: 'bf16x3', 6: 'bf16x6'}[code]
 
 
 class StylePlugin:

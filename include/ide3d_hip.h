@@ -347,11 +347,27 @@ typedef struct ide3d_modconv_params {
     int64_t w_batch_stride;   /* 0: one weight tensor for the batch (modulation via `styles` on the input);
                                  > 0: per-image weights w + n * w_batch_stride (styles already folded in by the caller:
                                  lets heads with different styles — toRGB + toSeg, networks.py:1109,1130 — share one launch) */
+    int32_t arith;            /* arithmetic of the shared-weight 3x3 layers: 0 = process default (ide3d_set_conv_arithmetic),
+                                 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (see ide3d_set_conv_arithmetic) */
 } ide3d_modconv_params;
 
 int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,
                                       int32_t per_image_weights);
 int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
+
+/*
+ * Arithmetic of the shared-weight 3x3 / transposed 3x3 layers on 16-pixel-wide tiles (everything else always runs on the
+ * fp32 MFMA).  The reference computes these layers with ATen's fp32 convolution (conv2d_gradfix.py:35,40), or in fp16 for
+ * the `num_fp16_res` highest resolutions of a released pickle (inversion/networks.py:1058-1060):
+ *   1  fp32 MFMA: exact fp32 products, fp32 accumulation (v_mfma_f32_32x32x2_f32);
+ *   6  bf16x6: each fp32 operand = 3 bf16 pieces, the 6 products above 2^-24 on v_mfma_f32_32x32x16_bf16, fp32 accumulation:
+ *      fp32-grade (per-product error <= ~2^-23 relative) at 6/16 of the fp32 MFMA time;
+ *   3  bf16x3: 2 pieces, 3 products, per-product error ~2^-17 relative, 3/16 of the time;
+ *   0  back to the process default (environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3).
+ * Packed weights in a modconv workspace are specific to the arithmetic they were packed for.
+ */
+int     ide3d_set_conv_arithmetic(int32_t arith);
+int32_t ide3d_get_conv_arithmetic(void);
 
 /* ---- per-layer style preparation ------------------------------------------------------------------ */
 /*
