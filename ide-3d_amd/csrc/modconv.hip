@@ -738,45 +738,45 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             unsigned b_base[K::NTW];
 #pragma unroll
             for (int j = 0; j < K::NTW; ++j) b_base[j] = b_base0[j] + xbuf * (K::X_UNITS * 16);
+            // Software pipeline over (tap, piece) groups: the A and B pieces q of tap kx are one group of MTW + NTW 16-byte reads;
+            // group s + 1 is in flight while the products that group s completes - (qa, qb) with max(qa, qb) = q and
+            // qa + qb < PARTS - multiply.  At most two groups (<= 12 reads) are outstanding: lgkmcnt is a 4-bit counter.
             u32x4 av[2][K::MTW][PARTS], bv[2][K::NTW][PARTS];
-            constexpr int NRD = (K::MTW + K::NTW) * PARTS;
-            auto issue = [&](auto kxx) {
-                constexpr int KX = decltype(kxx)::value, B = KX & 1, T = KY * 3 + KX;
-                static_for<PARTS>([&](auto qq) {
-                    constexpr int Q = decltype(qq)::value;
-                    static_for<K::MTW>([&](auto ii) {
-                        constexpr int I = decltype(ii)::value;
-                        av[B][I][Q] = lds_read128_async<(((KX * PARTS + Q) * 2) * K::BM + I * 32) * 16>(a_base);
-                    });
-                    static_for<K::NTW>([&](auto jj) {
-                        constexpr int J = decltype(jj)::value;
-                        bv[B][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
-                    });
+            constexpr int GRP = K::MTW + K::NTW, NGRP = 3 * PARTS;
+            static_assert(2 * GRP <= 15, "lgkmcnt is a 4-bit counter");
+            auto issue = [&](auto ss) {
+                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX & 1, T = KY * 3 + KX;
+                static_for<K::MTW>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    av[B][I][Q] = lds_read128_async<(((KX * PARTS + Q) * 2) * K::BM + I * 32) * 16>(a_base);
+                });
+                static_for<K::NTW>([&](auto jj) {
+                    constexpr int J = decltype(jj)::value;
+                    bv[B][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
                 });
             };
             issue(std::integral_constant<int, 0>{});
-            static_for<3>([&](auto kxx) {
-                constexpr int KX = decltype(kxx)::value, B = KX & 1, QC = tap_class<MODE>(KY * 3 + KX);
-                if constexpr (KX + 1 < 3) issue(std::integral_constant<int, KX + 1>{});
-                lds_wait128<(KX + 1 < 3) ? (NRD < 15 ? NRD : 15) : 0>(av[B][0][0]);
+            static_for<NGRP>([&](auto ss) {
+                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX & 1, QC = tap_class<MODE>(KY * 3 + KX);
+                if constexpr (S + 1 < NGRP) issue(std::integral_constant<int, S + 1>{});
+                lds_wait128<(S + 1 < NGRP) ? GRP : 0>(av[B][0][Q]);
 #pragma unroll
-                for (int q = 0; q < PARTS; ++q) {
+                for (int i = 0; i < K::MTW; ++i) lds_pin128(av[B][i][Q]);
 #pragma unroll
-                    for (int i = 0; i < K::MTW; ++i) lds_pin128(av[B][i][q]);
+                for (int j = 0; j < K::NTW; ++j) lds_pin128(bv[B][j][Q]);
 #pragma unroll
-                    for (int j = 0; j < K::NTW; ++j) lds_pin128(bv[B][j][q]);
-                }
-                // products a_qa * b_qb with qa + qb < PARTS, smallest terms first
+                for (int qa = 0; qa <= Q; ++qa)
 #pragma unroll
-                for (int sum = PARTS - 1; sum >= 0; --sum)
+                    for (int qb = 0; qb <= Q; ++qb) {
+                        if ((qa == Q || qb == Q) && qa + qb < PARTS) {
 #pragma unroll
-                    for (int qa = 0; qa <= sum; ++qa)
+                            for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
-                        for (int i = 0; i < K::MTW; ++i)
-#pragma unroll
-                            for (int j = 0; j < K::NTW; ++j)
-                                acc[QC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[B][i][qa]),
-                                                                                        __builtin_bit_cast(bf16x8, bv[B][j][sum - qa]), acc[QC][i][j], 0, 0, 0);
+                                for (int j = 0; j < K::NTW; ++j)
+                                    acc[QC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[B][i][qa]),
+                                                                                            __builtin_bit_cast(bf16x8, bv[B][j][qb]), acc[QC][i][j], 0, 0, 0);
+                        }
+                    }
             });
             if (KY == 2 && more) commit_patch(xbuf ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -821,6 +821,14 @@ template <int MODE, int BIG, int PH, int PARTS>
 __global__ void __launch_bounds__(256, (SpCfg<MODE, BIG, PH, PARTS>::LDS_BYTES <= 80 * 1024 && SpCfg<MODE, BIG, PH, PARTS>::NCLS * SpCfg<MODE, BIG, PH, PARTS>::MTW * SpCfg<MODE, BIG, PH, PARTS>::NTW <= 8) ? 2 : 1)
 modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
     using K = SpCfg<MODE, BIG, PH, PARTS>;
+#ifdef IDE3D_SP_EXCLUSIVE_SIMD
+    // Build option (make EXTRA=-DIDE3D_SP_EXCLUSIVE_SIMD): claim the whole register file of the SIMD so that no wave of ANOTHER
+    // kernel can sit beside this one.  Measured on MI355X: packed fp32 VALU instructions (v_pk_fma_f32 ...) of a foreign wave
+    // return wrong results while a wave on the same SIMD executes v_mfma_f32_32x32x16_bf16; this library contains none
+    // (csrc/Makefile), the option protects kernels of other libraries running on other streams.  Cost: configurations that
+    // otherwise hold two waves per SIMD lose 20-60 % (scripts/concurrency_check.py).
+    asm volatile("" ::: "v255", "a255");
+#endif
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
     modconv_split_tile<MODE, BIG, PH, PARTS>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
@@ -960,7 +968,8 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
     // split-bf16 loop: shared-weight 3x3 / all-class transposed layers on 16-pixel-wide tiles, 64- or 128-row blocks
     if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 &&
-        (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8) {
+        (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8 &&
+        (!getenv("IDE3D_MODCONV_SP_MODES") || (atoi(getenv("IDE3D_MODCONV_SP_MODES")) & (pl.mode == MODE_CONV3 ? 1 : 2)))) {
         pl.parts = (arith == 3) ? 2 : 3;
         static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
         if (pl.mode == MODE_CONV3) {
@@ -972,6 +981,12 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
             if (sp_rows == 8) pl.tile = 6;
             if (sp_rows == 16 && pl.big == 2) pl.tile = 7;
         }
+        static const int sp_maxlds = getenv("IDE3D_MODCONV_SP_MAXLDS") ? atoi(getenv("IDE3D_MODCONV_SP_MAXLDS")) : 0;
+        const int ph = (pl.tile == 4) ? 4 : (pl.tile == 0 || pl.tile == 6) ? 8 : 16;
+        const int lds = 2 * 16 * (3 * pl.parts * 2 * pl.bm + pl.parts * 2 * (ph + 2) * 18);
+        if (sp_maxlds && lds > sp_maxlds) pl.parts = 0;
+    }
+    if (pl.parts) {
         pl.kc = 16; pl.cchunks = cdiv(p.cin, 16);
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
     }

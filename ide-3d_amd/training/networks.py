@@ -88,6 +88,7 @@ def _wsq_t(weight):
 # The styles, demodulation coefficients and folded head weights of every layer depend only on `ws`, not on the
 # activations: `prefetch_styles` computes them up front on a side stream (43 small launches per synthesis pass that would
 # otherwise sit between the big convolution launches of the main stream) and the layers pick their result up by identity.
+import os
 import threading
 
 _tls = threading.local()  # .prefetched: {id(affine module) -> (w data_ptr, result, event)} of the synthesis pass running on this thread

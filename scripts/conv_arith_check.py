@@ -37,8 +37,8 @@ def accuracy(device):
     g = torch.Generator().manual_seed(7)
     rn = lambda *sh: torch.randn(*sh, generator=g).to(device)
     rows = []
-    for (n, cin, cout, h, w, mode) in ((2, 40, 72, 37, 45, 0), (1, 128, 128, 64, 64, 0), (3, 64, 200, 33, 20, 0), (2, 512, 64, 16, 16, 0),
-                                       (2, 40, 72, 37, 45, 2), (1, 128, 64, 64, 64, 2), (2, 96, 130, 20, 33, 2), (4, 512, 512, 16, 16, 2)):
+    for (n, cin, cout, h, w, mode) in ((2, 40, 72, 37, 45, 0), (1, 128, 128, 64, 64, 0), (3, 64, 200, 33, 20, 0), (2, 512, 64, 16, 16, 0), (4, 128, 128, 256, 256, 0), (4, 64, 64, 512, 512, 0),
+                                       (2, 40, 72, 37, 45, 2), (1, 128, 64, 64, 64, 2), (2, 96, 130, 20, 33, 2), (4, 512, 512, 16, 16, 2), (4, 128, 64, 256, 256, 2), (4, 256, 128, 128, 128, 2)):
         x = rn(n, cin, h, w); wt = rn(cout, cin, 3, 3) / math.sqrt(cin * 9); s = rn(n, cin) + 1; d = torch.rand(n, cout, generator=g).to(device) + 0.5
         ref = ref64(x, wt, s, d, mode)
         row = dict(shape=[n, cin, cout, h, w], mode=mode)
