@@ -230,6 +230,10 @@ def check_parity(render, device, tol=2e-3):
     return rec, (img, seg)
 
 
+ARITH_DTYPE = {'fp32': 'f32', 'bf16x6': 'f32 (3x3 convolutions: 3-way bf16 split operands, 6 products >= 2^-24, fp32 accumulate; all else f32)',
+               'bf16x3': 'f32 storage, 3x3 convolutions bf16x3 (2-way split operands, 3 products, ~2^-17 per product, fp32 accumulate)'}
+
+
 # ---- main ------------------------------------------------------------------------------------------------------------------------
 
 def main():
@@ -243,6 +247,9 @@ def main():
     ap.add_argument('--no-roofline-extra', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
+    ap.add_argument('--conv-arith', default='default', choices=['default', 'fp32', 'bf16x6', 'bf16x3'],
+                    help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h); default = the library default')
+    ap.add_argument('--no-arith-sweep', action='store_true', help='skip the short runs with the other conv arithmetics (N = 1 only)')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='launcher / protocol self-test without a GPU: tiny generator on CPU tensors, gloo backend (tests/test_bench_launcher_cpu.py)')
     args = ap.parse_args()
@@ -290,6 +297,9 @@ def main():
     if not cpu:
         from torch_utils import hip_plugin
         hip_plugin.load()     # hard error if the HIP library is missing
+        if args.conv_arith != 'default':
+            hip_plugin.conv_arithmetic(args.conv_arith)
+    arith = hip_plugin.conv_arithmetic() if hip_plugin else 'fp32'
 
     torch.manual_seed(0)  # same random-init weights on every rank
     G = triplane.TriPlaneGenerator(triplane.tiny_spec() if cpu else None).eval().to(device)
@@ -372,10 +382,11 @@ def main():
         out = {
             'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': frames_block / med, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH_DTYPE[arith], 'data': 'synthetic',
             'config': {'workload': 'gen_images.py-style: random-init ide3d-ffhq-64-512, G.mapping + G.synthesis (64 neural render -> 512, '
                                    '96 samples, RGB + 19-class seg) + uint8 frame conversion, batch = 4 seeds per GPU',
-                       'global_batch': BATCH * world, 'parallelism': f'dp{world} (one rank per GPU, RCCL gather of uint8 frames)'},
+                       'global_batch': BATCH * world, 'parallelism': f'dp{world} (one rank per GPU, RCCL gather of uint8 frames)',
+                       'conv_arithmetic': arith},
             'timing': {'blocks': len(block_s), 'steps_per_block': args.steps, 'reported': 'median block',
                        'ms_per_step_min': order[0] / args.steps * 1e3, 'ms_per_step_median': med / args.steps * 1e3,
                        'ms_per_step_max': order[-1] / args.steps * 1e3, 'frames_per_s_min': frames_block / order[-1],
@@ -397,6 +408,33 @@ def main():
             out['parity'], got = check_parity(render, device)
             out['parity_ok'] = out['parity'].get('ok')
             pin = parity_inputs()
+        if not cpu and world == 1 and not args.no_arith_sweep:
+            # the same step with the other arithmetics of the 3x3 layers: one captured graph and two short blocks each, parity against
+            # the same golden frames (nothing else changes: every other kernel is fp32 in all three)
+            sweep = {arith: {'frames_per_s': out['value'], 'ms_per_step': out['ms_per_step'], 'parity_max_rel_err': (out.get('parity') or {}).get('max_rel_err')}}
+            keep = graphed
+            for other in ('fp32', 'bf16x6', 'bf16x3'):
+                if other == arith:
+                    continue
+                hip_plugin.conv_arithmetic(other)
+                try:
+                    graphed = triplane.GraphedRenderer(G, BATCH, device) if keep is not None else None
+                    for i in range(3):
+                        step(done + i)
+                    ts = []
+                    for _b in range(2):
+                        sync(); t0 = time.perf_counter()
+                        for i in range(args.steps):
+                            step(done + i)
+                        sync(); ts.append(time.perf_counter() - t0)
+                    rec = {'frames_per_s': BATCH * args.steps / min(ts), 'ms_per_step': min(ts) / args.steps * 1e3}
+                    if not args.no_parity:
+                        rec['parity_max_rel_err'] = check_parity(render, device)[0].get('max_rel_err')
+                    sweep[other] = rec
+                finally:
+                    graphed = keep
+                    hip_plugin.conv_arithmetic(args.conv_arith)
+            out['by_conv_arithmetic'] = sweep
         if not cpu and not args.no_roofline:
             out['roofline'] = bench_gather(device)
         if not cpu and world == 1 and not args.no_roofline_extra:

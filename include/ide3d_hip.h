@@ -327,7 +327,9 @@ int ide3d_density_lattice(const ide3d_render_params* p, const ide3d_lattice* lat
  * x [n, cin, h, w], y [n, cout, h, w] NCHW contiguous float32; w [cout, cin, k, k];
  * styles s [n, cin]; dcoefs d [n, cout] or NULL (no demodulation); noise [h, w] or NULL;
  * bias [cout] or NULL.  act: 1 linear, 3 lrelu (bias_act cuda_idx).  k in {1, 3}.
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 adds).
+ * fp32 in / fp32 out / fp32 accumulate.  1x1, per-image-weight, stride-2 and narrow (< 64 output channels, < 12 pixels) layers run
+ * on v_mfma_f32_32x32x2_f32 (exact fp32 products); the shared-weight 3x3 and transposed 3x3 layers run in the arithmetic
+ * selected by `arith` / ide3d_set_conv_arithmetic() below.
  */
 typedef struct ide3d_modconv_params {
     const float* x; const float* w; const float* styles; const float* dcoefs;
@@ -363,7 +365,8 @@ int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
  *   6  bf16x6: each fp32 operand = 3 bf16 pieces, the 6 products above 2^-24 on v_mfma_f32_32x32x16_bf16, fp32 accumulation:
  *      fp32-grade (per-product error <= ~2^-23 relative) at 6/16 of the fp32 MFMA time;
  *   3  bf16x3: 2 pieces, 3 products, per-product error ~2^-17 relative, 3/16 of the time;
- *   0  back to the process default (environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3).
+ *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3, else bf16x6 (measured against a
+ *      float64 convolution its error equals the fp32 MFMA's: max 1.3e-6 vs 1.4e-6 of max |y| at 128 -> 128 @256).
  * Packed weights in a modconv workspace are specific to the arithmetic they were packed for.
  */
 int     ide3d_set_conv_arithmetic(int32_t arith);

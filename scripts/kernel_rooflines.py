@@ -6,7 +6,8 @@
 For every case: HIP-event time of `iters` launches replayed from one hipGraph (no host launch gaps; `--eager` launches
 them one by one instead: that is the mode the rocprofv3 counter passes of scripts/pmc_kernels.sh use), the ALGORITHMIC bytes
 or flops of SURVEY.md §8(d) (`(in + out) * sizeof` for streaming ops, `2 * Cin * Cout * k^2 * positions` for convolutions),
-and the achieved fraction of the bounding peak (HBM 8.0 TB/s spec, fp32 MFMA 157.3 TFLOP/s).
+and the achieved fraction of the bounding peak (HBM 8.0 TB/s spec, fp32 MFMA 157.3 TFLOP/s; a split-bf16 convolution row is
+priced against the dense bf16 MFMA peak 2.5 PFLOP/s divided by its 6 or 3 bf16 products per fp32 product).
 `bench.py` embeds the same rows as `roofline_extra`; the committed table lives under profiles/.
 """
 
@@ -28,6 +29,8 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12
 HBM_COPY = 6.29e12           # measured copy ceiling (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK = 157.3e12
+BF16_MFMA_PEAK = 2.5e15      # dense; the split-bf16 convolutions spend 6 (bf16x6) or 3 (bf16x3) bf16 products per fp32 product
+ARITH_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}
 N = 4                        # batch of config 2
 
 
@@ -186,20 +189,27 @@ def cases(device):
     # ---- a7 modulated convolutions (every mode) ----------------------------------------------------------------------------
     mc = hip_plugin.ModconvPlugin.modconv2d
 
-    def conv_case(tag, cin, cout, res, k=3, mode=0):
+    ARITH_CODE = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6}
+
+    def conv_case(tag, cin, cout, res, k=3, mode=0, ariths=('bf16x6', 'fp32')):
+        """One row per arithmetic for the layers that have a choice (3x3 stride 1 and transposed); the bound of a split-bf16 row is
+        the bf16 MFMA peak / its products per fp32 product ('mfma:bf16x6' = 416.7 TFLOP/s of fp32-equivalent work)."""
         xx = rn(N, cin, res, res); ww = rn(cout, cin, k, k); ss = rn(N, cin) + 1; dc = torch.rand(N, cout, generator=g).to(device)
-        if mode == 0:
-            nzz = rn(res, res); bz = rn(cout)
-            fn = lambda: mc(xx, ww, ss, dc, nzz, 1.0, bz, 3, 0.2, math.sqrt(2), -1.0)
-            pos = res * res
-        elif mode == 2:
-            fn = lambda: mc(xx, ww, ss, dc, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
-            pos = res * res
-        else:
+        if mode == 1:
             bz = rn(cout)
             fn = lambda: mc(xx, ww, None, None, None, 0.0, bz, 3, 0.2, math.sqrt(2), -1.0, mode=1)
             pos = ((res - 3) // 2 + 1) ** 2
-        out.append((tag, 'modconv_kernel', 'mfma', 2 * cin * cout * k * k * pos * N, fn))
+            out.append((tag, 'modconv_kernel', 'mfma', 2 * cin * cout * k * k * pos * N, fn))
+            return
+        for ar in ariths:
+            code = ARITH_CODE[ar]
+            if mode == 0:
+                nzz = rn(res, res); bz = rn(cout)
+                fn = lambda code=code, nzz=nzz, bz=bz: mc(xx, ww, ss, dc, nzz, 1.0, bz, 3, 0.2, math.sqrt(2), -1.0, arith=code)
+            else:
+                fn = lambda code=code: mc(xx, ww, ss, dc, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, arith=code)
+            kern = 'modconv_kernel' if ar == 'fp32' else 'modconv_split_kernel'
+            out.append((f'{tag} [{ar}]', kern, 'mfma' if ar == 'fp32' else f'mfma:{ar}', 2 * cin * cout * k * k * res * res * N, fn))
 
     conv_case('modconv 3x3 128->128 @256', 128, 128, 256)
     conv_case('modconv 3x3 256->256 @128', 256, 256, 128)
@@ -239,9 +249,14 @@ def measure_all(device, iters=20, only=None, eager=False):
         if bound == 'hbm':
             rows.append(dict(name=name, kernel=kernel, bound='hbm', us=us, algorithmic_bytes=amount, achieved=rate / 1e9, peak=HBM_PEAK / 1e9,
                              unit='GB/s', frac=rate / HBM_PEAK, frac_of_copy_ceiling=rate / HBM_COPY))
-        else:
+        elif bound == 'mfma':
             rows.append(dict(name=name, kernel=kernel, bound='mfma', us=us, algorithmic_flops=amount, achieved=rate / 1e12, peak=FP32_MFMA_PEAK / 1e12,
                              unit='TFLOP/s', frac=rate / FP32_MFMA_PEAK))
+        else:
+            # split-bf16 convolution: fp32-equivalent flops against the bf16 MFMA peak / products per fp32 product
+            peak = BF16_MFMA_PEAK / ARITH_PRODUCTS[bound.split(':')[1]]
+            rows.append(dict(name=name, kernel=kernel, bound=bound, us=us, algorithmic_flops=amount, achieved=rate / 1e12, peak=peak / 1e12,
+                             unit='TFLOP/s', frac=rate / peak, frac_of_fp32_mfma_peak=rate / FP32_MFMA_PEAK))
     return rows
 
 
