@@ -550,16 +550,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MODE, int BIG, int PH, int PARTS>
+// WBUF: weight stage buffers (2 = the next stage streams in behind the MFMAs; 1 = two workgroups per CU hide each other's staging).
+// NWV: 4 waves (2 x 2), or 8 waves (2 x 4, two per SIMD) with time-shifted roles: waves 0-3 stage the patch and start multiplying at
+// once, waves 4-7 first issue the weight DMA of the next stage (the issuing wave is stuck for most of the transfer, ~19 B/clk/CU)
+// and multiply afterwards: the matrix pipe of every SIMD always has one of the two to take instructions from.
+template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV_ = 4>
 struct SpCfg {
     static_assert(MODE == MODE_CONV3 || MODE == MODE_TCONV3A, "split-bf16 loop: 3x3 and all-class transposed 3x3 only");
     static_assert(BIG == 1 || BIG == 2, "64- or 128-row blocks");
-    static constexpr int PW = 16, NT = 256, NWV = 4;
+    static_assert(NWV_ == 4 || NWV_ == 8, "4 or 8 waves");
+    static constexpr int PW = 16, NWV = NWV_, NT = 64 * NWV;
     static constexpr int BN = PH * PW;
     static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;
-    static constexpr int WM = 2, WN = 2;
-    static constexpr int MTW = (BIG == 1) ? 2 : 1, NTW = BN / 64;
-    static_assert(NTW >= 1, "at least 64 pixels");
+    static constexpr int WM = 2, WN = NWV / 2;
+    static constexpr int MTW = (BIG == 1) ? 2 : 1, NTW = BN / 32 / WN;
+    static_assert(NTW >= 1 && NTW * 32 * WN == BN, "pixel tile must split into 32-pixel MFMA tiles per wave");
+    static constexpr int NLOAD = 4;                                  // waves that stage (patch: waves 0-3; weights: the last four)
     static constexpr int BM = 64 * MTW;
     static constexpr int KC = 16;
     static constexpr int HP = PH + 2, HW = PW + 2, NSLOT = HP * HW;
@@ -567,7 +573,7 @@ struct SpCfg {
     static constexpr int W_UNITS = 3 * PARTS * 2 * BM;               // 16-byte units per weight stage (one kernel row)
     static constexpr int X_UNITS = PARTS * 2 * NSLOT;                // per patch buffer
     static constexpr int NXR = (NSLOT + 63) / 64;                    // patch pixels per lane
-    static constexpr int LDS_BYTES = 2 * 16 * (W_UNITS + X_UNITS);
+    static constexpr int LDS_BYTES = 16 * (WBUF * W_UNITS + 2 * X_UNITS);
 };
 
 __host__ __device__ inline int64_t sp_packed_units(int mblocks, int cchunks, int bm, int parts) { return (int64_t)mblocks * cchunks * 9 * parts * 2 * bm; }
@@ -629,10 +635,10 @@ template <int PENDING>
 __device__ __forceinline__ void lds_wait128(u32x4& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
 __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int BIG, int PH, int PARTS>
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
                                                    const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x) {
-    using K = SpCfg<MODE, BIG, PH, PARTS>;
+    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     constexpr int PW = K::PW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -642,8 +648,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const int txi = tl % tiles_x, tyi = tl / tiles_x;
     const int y0 = tyi * PH, x0 = txi * PW;
     const int n0 = grp;                                                                 // one image per tile
-    u32x4* const s_w = reinterpret_cast<u32x4*>(smem);                                  // [2][W_UNITS]
-    u32x4* const s_x = s_w + 2 * K::W_UNITS;                                            // [2][X_UNITS]
+    u32x4* const s_w = reinterpret_cast<u32x4*>(smem);                                  // [WBUF][W_UNITS]
+    u32x4* const s_x = s_w + WBUF * K::W_UNITS;                                         // [2][X_UNITS]
 
     f32x16 acc[K::NCLS][K::MTW][K::NTW];
 #pragma unroll
@@ -668,7 +674,9 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const float* __restrict__ ximg = p.x + (int64_t)n0 * p.cin * hw;
     float xreg[K::NXR][4];
     float sty[4];
+    const bool stages_patch = (NWV == 4) || wid < 4;
     auto fetch_patch = [&](int c) {
+        if (!stages_patch) return;
         const int ci0 = c * K::KC + wid * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -679,6 +687,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
         }
     };
     auto commit_patch = [&](int buf) {
+        if (!stages_patch) return;
         unsigned char* const dst = reinterpret_cast<unsigned char*>(s_x + buf * K::X_UNITS) + ((wid >> 1) * K::NSLOT) * 16 + (wid & 1) * 8;
 #pragma unroll
         for (int r = 0; r < K::NXR; ++r) {
@@ -702,7 +711,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     static_assert(K::W_UNITS % 64 == 0, "weight stage is a whole number of 1 KB pieces");
     auto fetch_weights = [&](int stage, int buf) {
         const u32x4* src = wsrc + (int64_t)stage * K::W_UNITS;
-        for (int i = wid; i < W_PIECES; i += K::NWV)
+        if (NWV == 8 && wid < 4) return;
+        for (int i = wid & 3; i < W_PIECES; i += 4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(s_w + buf * K::W_UNITS + i * 64), 16, 0, 0);
     };
@@ -723,7 +733,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
     if (c_begin < c_end) {
-        fetch_weights(c_begin * 3, 0);
+        if (WBUF == 2) fetch_weights(c_begin * 3, 0);
         fetch_patch(c_begin);
         commit_patch(0);
     }
@@ -740,11 +750,20 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
         static_for<3>([&](auto kyy) {
             constexpr int KY = decltype(kyy)::value;
             IDE3D_MC_TS(0)
-            if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1);
-            if (KY == 1 && more) fetch_patch(c + 1);
+            if constexpr (WBUF == 2) {
+                if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1);
+                if (KY == 1 && more) fetch_patch(c + 1);
+            } else {
+                // one weight buffer: this stage's slab is fetched now (everybody left the previous stage at the barrier below); the
+                // other workgroup of the CU multiplies meanwhile
+                fetch_weights(c * 3 + KY, 0);
+                if (KY == 1 && more) fetch_patch(c + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             IDE3D_MC_TS(1)
             // ---- MFMAs of kernel row KY: taps pipelined (operands of tap kx + 1 in flight while tap kx multiplies) ----
-            const unsigned a_base = a_base0 + wbuf * (K::W_UNITS * 16);
+            const unsigned a_base = a_base0 + ((WBUF == 2) ? wbuf * (K::W_UNITS * 16) : 0);
             unsigned b_base[K::NTW];
 #pragma unroll
             for (int j = 0; j < K::NTW; ++j) b_base[j] = b_base0[j] + xbuf * (K::X_UNITS * 16);
@@ -791,7 +810,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             IDE3D_MC_TS(2)
             if (KY == 2 && more) commit_patch(xbuf ^ 1);
             IDE3D_MC_TS(3)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (WBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             IDE3D_MC_TS(4)
             __syncthreads();
             IDE3D_MC_TS(5)
@@ -843,23 +862,15 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 }
 
 
-template <int MODE, int BIG, int PH, int PARTS>
-__global__ void __launch_bounds__(256, (SpCfg<MODE, BIG, PH, PARTS>::LDS_BYTES <= 80 * 1024 && SpCfg<MODE, BIG, PH, PARTS>::NCLS * SpCfg<MODE, BIG, PH, PARTS>::MTW * SpCfg<MODE, BIG, PH, PARTS>::NTW <= 8) ? 2 : 1)
+template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV, (NWV == 8) ? 2 : (SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::LDS_BYTES <= 80 * 1024 &&
+                                  (WBUF == 1 || SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::NCLS * SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::MTW * SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::NTW <= 8)) ? 2 : 1)
 modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
-    using K = SpCfg<MODE, BIG, PH, PARTS>;
-#ifdef IDE3D_SP_EXCLUSIVE_SIMD
-    // Build option (make EXTRA=-DIDE3D_SP_EXCLUSIVE_SIMD): claim the whole register file of the SIMD so that no wave of ANOTHER
-    // kernel can sit beside this one.  Measured on MI355X: packed fp32 VALU instructions (v_pk_fma_f32 ...) of a foreign wave
-    // return wrong results while a wave on the same SIMD executes v_mfma_f32_32x32x16_bf16; this library contains none
-    // (csrc/Makefile), the option protects kernels of other libraries running on other streams.  Cost: configurations that
-    // otherwise hold two waves per SIMD lose 20-60 % (scripts/concurrency_check.py).
-    asm volatile("" ::: "v255", "a255");
-#endif
+    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
-    modconv_split_tile<MODE, BIG, PH, PARTS>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
+    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
 }
-
 
 // reduce split-K partials + epilogue
 __global__ void __launch_bounds__(256)
@@ -1074,8 +1085,19 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
     if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g); }
-    else if (pl.tile == 0 || pl.tile == 6) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
-    else if constexpr (MODE == MODE_CONV3 || BIG == 2) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+    else if (pl.tile == 0 || pl.tile == 6) {
+        // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
+        static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr;
+        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+    }
+    else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
+        // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6;
+        // the all-class transposed form keeps 4 waves: 279 vs 268 us); IDE3D_MODCONV_SP_W4 = 4 waves everywhere
+        static const bool eight = getenv("IDE3D_MODCONV_SP_W4") == nullptr && MODE == MODE_CONV3;
+        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+    }
 }
 
 }  // namespace ide3d

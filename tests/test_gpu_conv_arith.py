@@ -73,7 +73,7 @@ def test_default_arithmetic_switch(gpu_device):
     from torch_utils import hip_plugin
     before = hip_plugin.conv_arithmetic()
     try:
-        x, w, s, d = _operands((1, 32, 64, 20, 20, 0), gpu_device)
+        x, w, s, d = _operands((1, 64, 64, 20, 20, 0), gpu_device)      # cin > 32: narrower layers always take the fp32 loop
         outs = {}
         for name, code in ARITH.items():
             assert hip_plugin.conv_arithmetic(name) == name
