@@ -709,12 +709,22 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const u32x4* __restrict__ wsrc = wp + (int64_t)mb * g.cchunks * 3 * K::W_UNITS;
     constexpr int W_PIECES = K::W_UNITS / 64;                        // 1 KB pieces (64 lanes x 16 bytes)
     static_assert(K::W_UNITS % 64 == 0, "weight stage is a whole number of 1 KB pieces");
-    auto fetch_weights = [&](int stage, int buf) {
+    // An LDS-DMA piece costs the issuing wave 200-350 cycles (the stream runs at ~3-5 B/clk per issuing wave), so the 8-wave form
+    // splits the pieces in time: waves 4-7 issue the first W_EARLY of their column before they multiply (waves 0-3 multiply
+    // meanwhile), waves 0-3 issue the rest after their MFMAs and the patch commit (waves 4-7 multiply meanwhile).
+    constexpr int W_COL = (W_PIECES + 3) / 4;                        // pieces per wave column (wid & 3)
+    constexpr int W_EARLY = (NWV == 8) ? (W_COL * 5 + 8) / 9 : W_COL;
+    auto fetch_weights = [&](int stage, int buf, bool late = false) {
         const u32x4* src = wsrc + (int64_t)stage * K::W_UNITS;
-        if (NWV == 8 && wid < 4) return;
-        for (int i = wid & 3; i < W_PIECES; i += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(s_w + buf * K::W_UNITS + i * 64), 16, 0, 0);
+        if (NWV == 4 && late) return;
+        if (NWV == 8 && (late != (wid < 4))) return;
+        const int m0 = late ? W_EARLY : 0, m1 = late ? W_COL : W_EARLY;
+        for (int m = m0; m < m1; ++m) {
+            const int i = (wid & 3) + 4 * m;
+            if (i < W_PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(s_w + buf * K::W_UNITS + i * 64), 16, 0, 0);
+        }
     };
 
     // ---- operand addresses ----
@@ -733,7 +743,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
     if (c_begin < c_end) {
-        if (WBUF == 2) fetch_weights(c_begin * 3, 0);
+        if (WBUF == 2) { fetch_weights(c_begin * 3, 0); if (NWV == 8) fetch_weights(c_begin * 3, 0, true); }
         fetch_patch(c_begin);
         commit_patch(0);
     }
@@ -809,6 +819,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             });
             IDE3D_MC_TS(2)
             if (KY == 2 && more) commit_patch(xbuf ^ 1);
+            if constexpr (WBUF == 2 && NWV == 8) { if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1, true); }
             IDE3D_MC_TS(3)
             if (WBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             IDE3D_MC_TS(4)
@@ -822,11 +833,12 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 #endif
     modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp);
 #ifdef IDE3D_MC_TRACE
-    if (blockIdx.x == 100 && threadIdx.x == 0) {
-        for (int k = 0; k < 6; ++k) g_mc_dbg[k] = mc_acc[k];
-        g_mc_dbg[7] = (unsigned long long)(c_end - c_begin) * 3;
-        g_mc_dbg[8] = mc_prologue;
-        g_mc_dbg[9] = __builtin_readcyclecounter() - mc_t1;
+    if (blockIdx.x == 100 && (threadIdx.x == 0 || threadIdx.x == 256)) {          // wave 0 (and wave 4 of an 8-wave workgroup, at [16..])
+        const int o = threadIdx.x ? 16 : 0;
+        for (int k = 0; k < 6; ++k) g_mc_dbg[o + k] = mc_acc[k];
+        g_mc_dbg[o + 7] = (unsigned long long)(c_end - c_begin) * 3;
+        g_mc_dbg[o + 8] = mc_prologue;
+        g_mc_dbg[o + 9] = __builtin_readcyclecounter() - mc_t1;
     }
 #endif
 }

@@ -18,8 +18,11 @@ buf = (ctypes.c_ulonglong * 256)()
 lib = hip_plugin.load()
 lib.ide3d_debug_mc.argtypes = [ctypes.c_void_p]
 assert lib.ide3d_debug_mc(buf) == 0
-st = max(int(buf[7]), 1)
 names = ('loop head', 'staging issue (DMA + patch loads)', 'operand reads + MFMA', 'commit', 'vmcnt(0)', 'barrier')
-tot = sum(buf[k] for k in range(6))
-print(f'{kind} {cin}->{cout} @{res} arith {arith}: {st} stages, {tot / st:.0f} cycles per stage: ' +
-      ', '.join(f'{nm} {buf[k] / st:.0f}' for k, nm in enumerate(names)) + f'; prologue {buf[8]}, epilogue issue {buf[9]}')
+for o, wave in ((0, 'wave 0'), (16, 'wave 4')):
+    st = int(buf[o + 7])
+    if not st:
+        continue
+    tot = sum(buf[o + k] for k in range(6))
+    print(f'{kind} {cin}->{cout} @{res} arith {arith} {wave}: {st} stages, {tot / st:.0f} cycles per stage: ' +
+          ', '.join(f'{nm} {buf[o + k] / st:.0f}' for k, nm in enumerate(names)) + f'; prologue {buf[o + 8]}, epilogue issue {buf[o + 9]}')
