@@ -874,11 +874,29 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 }
 
 
+// Build option (make EXTRA=-DIDE3D_SP_EXCLUSIVE_SIMD): every split-bf16 workgroup claims the whole register file of its SIMDs (512
+// registers for a 4-wave workgroup's wave, 256 for each of the two waves an 8-wave workgroup puts on a SIMD), so that no wave of
+// ANOTHER kernel can sit beside a bf16 MFMA wave.  Measured on MI355X: packed fp32 VALU instructions (v_pk_fma_f32 ...) of a
+// foreign wave return wrong results while a wave on the same SIMD executes v_mfma_f32_32x32x16_bf16; this library contains none
+// (csrc/Makefile), the option protects kernels of other libraries on other streams.  Cost: configurations that otherwise hold two
+// workgroups per CU lose 20-60 %.
+#ifdef IDE3D_SP_EXCLUSIVE_SIMD
+constexpr bool kSpExclusive = true;
+#else
+constexpr bool kSpExclusive = false;
+#endif
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV>
+constexpr int sp_waves_per_simd() {
+    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
+    return (NWV == 8) ? 2 : (!kSpExclusive && K::LDS_BYTES <= 80 * 1024 && (WBUF == 1 || K::NCLS * K::MTW * K::NTW <= 8)) ? 2 : 1;
+}
 template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4>
-__global__ void __launch_bounds__(64 * NWV, (NWV == 8) ? 2 : (SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::LDS_BYTES <= 80 * 1024 &&
-                                  (WBUF == 1 || SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::NCLS * SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::MTW * SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>::NTW <= 8)) ? 2 : 1)
+__global__ void __launch_bounds__(64 * NWV, (sp_waves_per_simd<MODE, BIG, PH, PARTS, WBUF, NWV>()))
 modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
+#ifdef IDE3D_SP_EXCLUSIVE_SIMD
+    if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255");
+#endif
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
     modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
