@@ -1,4 +1,6 @@
-// modconv.hip — StyleGAN2 modulated convolutions as fp32-MFMA implicit GEMMs with fused epilogues.
+// modconv.hip — StyleGAN2 modulated convolutions as implicit GEMMs on the matrix cores with fused epilogues: an fp32-MFMA loop for
+// every shape (described first) and a split-bf16 loop (bf16x6 / bf16x3 on v_mfma_f32_32x32x16_bf16, further down) that the big
+// shared-weight 3x3 and transposed 3x3 layers take by default.
 //
 // Replaces the ATen convolutions behind `conv2d_gradfix.conv2d / conv_transpose2d`
 // (torch_utils/ops/conv2d_gradfix.py:35,40) for the three shapes the generator uses, as called from
@@ -29,7 +31,8 @@
 //     read, so the prefetch latency overlaps the MFMAs (+3 % frames/s); phase cycles: scripts/modconv_trace.py;
 //   * split-K (low-resolution 512-channel layers have too few tiles to fill 256 CUs): partial sums go to a
 //     workspace, `modconv_epilogue_kernel` reduces them and applies the epilogue — deterministic, no atomics.
-// Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.
+// Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.  The split-bf16 loop is bound by the bf16 MFMA
+// (2.5 PFLOP/s / 6 products) and, below 16 x 16-pixel tiles, by its weight stream.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
