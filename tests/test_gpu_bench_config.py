@@ -201,3 +201,24 @@ def test_renderer_falls_back_for_uncompiled_decoder_width(gpu_device):
     with pytest.raises(RuntimeError, match='tex_w0'):
         vr._plugin.sample_voxel(tex.contiguous(memory_format=torch.channels_last), geo.contiguous(memory_format=torch.channels_last),
                                 bad, torch.zeros(2, 4, 3, device=gpu_device))
+
+
+def test_bench_parity_fixture_per_conv_arithmetic(bench_generator, gpu_device):
+    """The frames `bench.py` counts, in every arithmetic of the 3x3 convolutions, against the oracle fixture the bench line itself
+    uses (`parity`, tests/golden/bench_parity.npz): fp32 MFMA and the default bf16x6 agree with the CPU oracle to fp32 rounding
+    (stated tolerance 2e-5 of the value range, measured 3e-6 for both); bf16x3 to 1e-4 (measured 1.4e-5)."""
+    import bench
+    from torch_utils import hip_plugin
+    from training import triplane
+    G, _sd = bench_generator
+    errs = {}
+    try:
+        for arith, tol in (('fp32', 2e-5), ('bf16x6', 2e-5), ('bf16x3', 1e-4)):
+            hip_plugin.conv_arithmetic(arith)
+            run = triplane.GraphedRenderer(G, 4, gpu_device)
+            rec, _ = bench.check_parity(lambda z, c_cond, c_cam, jitter: run(z, c_cond, c_cam, jitter=jitter), gpu_device, tol=tol)
+            assert rec['ok'], f'{arith}: {rec}'
+            errs[arith] = max(rec['max_rel_err'].values())
+    finally:
+        hip_plugin.conv_arithmetic('default')
+    assert errs['bf16x6'] < 2 * errs['fp32'] + 1e-6, f'bf16x6 is not fp32-grade at frame level: {errs}'
