@@ -847,6 +847,140 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// per-image 1x1 heads on the split-bf16 arithmetic
+// ------------------------------------------------------------------------------------------------
+// The dual toRGB + toSeg heads (per-image folded weights [n, O, C], bias, clamp; networks.py:1109,1130) are fp32-MFMA bound on the
+// loop above (56 % pipe busy at O = 192: 2.9x their HBM time).  Here a workgroup owns ALL O rows (MT x 32, MT = 1 or 6) of 128
+// consecutive pixels, so the activations are read once: wave w takes the B operand of its 32 pixels straight from global memory
+// (lane = pixel, 8 channels of its k half = 8 coalesced dword loads), splits it into bf16 pieces in registers and multiplies it
+// with the A fragments of all MT row tiles, which the four waves share through LDS (pre-split packed weights [chunk][piece][k half]
+// [row][8], double-buffered LDS-DMA).  The accumulator layout has lane = pixel, so every store instruction writes 128-byte runs.
+template <int PARTS, int MT>
+struct HeadCfg {
+    static constexpr int ROWS = MT * 32;
+    static constexpr int A_UNITS = PARTS * 2 * ROWS;                  // 16-byte units per 16-channel chunk
+    static constexpr int BN = 128;
+};
+__host__ __device__ inline int64_t head_packed_units(int n, int cchunks, int parts, int mt) { return (int64_t)n * cchunks * parts * 2 * mt * 32; }
+
+template <int PARTS>
+__global__ void __launch_bounds__(256)
+head_pack_split_kernel(const float* __restrict__ w, int64_t w_batch_stride, int n, int cout, int cin, int rows, int cchunks, u32x4* __restrict__ out) {
+    const int64_t total = (int64_t)n * cchunks * 2 * rows;            // one thread per (image, chunk, k half, row): all pieces
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int64_t r = i;
+        const int row = (int)(r % rows); r /= rows;
+        const int kg = (int)(r % 2); r /= 2;
+        const int cc = (int)(r % cchunks); r /= cchunks;
+        const int nb = (int)r;
+        unsigned pk[4][PARTS];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = cc * 16 + kg * 8 + e * 2;
+            const float a = (row < cout && ci < cin) ? w[nb * w_batch_stride + (int64_t)row * cin + ci] : 0.f;
+            const float b = (row < cout && ci + 1 < cin) ? w[nb * w_batch_stride + (int64_t)row * cin + ci + 1] : 0.f;
+            split_pair<PARTS>(a, b, pk[e]);
+        }
+        const int64_t base = (((int64_t)nb * cchunks + cc) * PARTS * 2 + kg) * rows + row;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) {
+            const u32x4 v = {pk[0][q], pk[1][q], pk[2][q], pk[3][q]};
+            out[base + (int64_t)q * 2 * rows] = v;
+        }
+    }
+}
+
+template <int PARTS, int MT>
+__global__ void __launch_bounds__(256, 2)        // MT = 6 needs ~170 registers: a third workgroup per CU spills (measured 264 vs 114 us)
+head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchunks, int tiles_per_image) {
+    using K = HeadCfg<PARTS, MT>;
+    constexpr int S_UNITS = (2 * K::A_UNITS > 512) ? 2 * K::A_UNITS : 512;   // >= 8 KB: the epilogue's staging tiles
+    __shared__ __attribute__((aligned(16))) u32x4 s_a[S_UNITS];              // weights of chunk c and c + 1 (L2-resident, one chunk of look-ahead)
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = bid / tiles_per_image, tile = bid % tiles_per_image;
+    const int hw = p.h * p.w_;
+    const int pix = tile * K::BN + wid * 32 + l32;
+    const int pix_c = min(pix, hw - 1);
+    const float* __restrict__ xl = p.x + (int64_t)n0 * p.cin * hw + (int64_t)(8 * half) * hw + pix_c;     // this lane's k half, channel 0 of chunk 0
+    const u32x4* __restrict__ wsrc = wp + (int64_t)n0 * cchunks * K::A_UNITS;
+
+    f32x16 acc[1][MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][m][0][r] = 0.f;
+
+    constexpr int A_PIECES = K::A_UNITS / 64;
+    static_assert(K::A_UNITS % 64 == 0, "whole 1 KB pieces");
+    auto fetch_a = [&](int c, int buf) {
+        for (int i = wid; i < A_PIECES; i += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (int64_t)c * K::A_UNITS + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(s_a + buf * K::A_UNITS + i * 64), 16, 0, 0);
+    };
+    // B operand ring: three register slots (chunk c in use, c + 1 and c + 2 in flight); the chunk loop is unrolled by three so that the
+    // slot of every access is a compile-time constant (a run-time slot index sends the ring to scratch memory)
+    float xr[3][8];
+    auto fetch_b = [&](int c, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = c * 16 + 8 * half + e;
+            const float v = xl[(int64_t)(min(ch, p.cin - 1) - 8 * half) * hw];      // clamped address, zero beyond cin (like the packed weights)
+            xr[SLOT][e] = (ch < p.cin) ? v : 0.f;
+        }
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    // issue order: A0 B0 B1 | A1 B2 | A2 B3 | ...: the activations (HBM) run two chunks ahead in registers, the weights one chunk ahead in LDS
+    fetch_a(0, 0); fetch_b(0, S0{});
+    if (cchunks > 1) fetch_b(1, S1{});
+    auto chunk = [&](int c, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value, NSLOT = (SLOT + 2) % 3;
+        // A(c) and B(c) have landed once at most the 8 loads of B(c + 1), issued after them, are outstanding
+        if (c + 1 < cchunks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // ... for every wave; and nobody still reads the buffer refilled below
+        if (c + 1 < cchunks) fetch_a(c + 1, (c + 1) & 1);
+        if (c + 2 < cchunks) fetch_b(c + 2, std::integral_constant<int, NSLOT>{});
+        u32x4 bfrag[PARTS];
+        {
+            unsigned pk[4][PARTS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair<PARTS>(xr[SLOT][2 * e], xr[SLOT][2 * e + 1], pk[e]);
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) bfrag[q] = u32x4{pk[0][q], pk[1][q], pk[2][q], pk[3][q]};
+        }
+        const u32x4* sa = s_a + (c & 1) * K::A_UNITS + half * K::ROWS + l32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            u32x4 af[PARTS];
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) af[q] = sa[q * 2 * K::ROWS + m * 32];
+#pragma unroll
+            for (int qa = 0; qa < PARTS; ++qa)
+#pragma unroll
+                for (int qb = 0; qa + qb < PARTS; ++qb)
+                    acc[0][m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[qa]), __builtin_bit_cast(bf16x8, bfrag[qb]), acc[0][m][0], 0, 0, 0);
+        }
+    };
+    for (int c = 0; c < cchunks; c += 3) {
+        chunk(c, S0{});
+        if (c + 1 < cchunks) chunk(c + 1, S1{});
+        if (c + 2 < cchunks) chunk(c + 2, S2{});
+    }
+    // epilogue: the shared one (bias, gain, clamp; rows staged through LDS so that a lane stores 16 bytes of one row) on the flattened
+    // image: one row of h * w pixels, this workgroup's 128-pixel run
+    __syncthreads();                                                         // every wave has finished reading the weight ring
+    ide3d_modconv_params pf = p;
+    pf.h = 1; pf.w_ = hw;
+    ConvGeom g{};
+    g.oh = 1; g.ow = hw; g.split_k = 1;
+    modconv_finish<MODE_CONV1, 1, 1, K::BN, 4, 1, MT, 1, K::ROWS, S_UNITS * 4>(pf, nullptr, g, acc, reinterpret_cast<float*>(s_a), 0, n0, 0, tile * K::BN, 0, 0, 0, wid, l32);
+}
+
 // ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
 struct BlockId { int mb, tile, grp, split; };
 __device__ __forceinline__ BlockId decode_block(const ConvGeom& g) {
@@ -1135,6 +1269,15 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
 
 }  // namespace ide3d
 
+// per-image 1x1 convolution without modulation / noise, linear, <= 32 or 161..192 outputs: the dual heads
+static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
+    static const bool off = getenv("IDE3D_MODCONV_HEAD_FP32") != nullptr;
+    return !off && arith != 1 && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 &&
+           (p.cout <= 32 || (p.cout > 160 && p.cout <= 192)) && p.cin >= 32 &&
+           (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 128) >= 2 * ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
+                                                                              // (512 channels @32^2 / @64^2: 54 us against 16 / 40 us on the fp32 loop)
+}
+
 static int check_modconv(const ide3d_modconv_params& p) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(p.n > 0 && p.cin > 0 && p.cout > 0 && p.h > 0 && p.w_ > 0, "modconv2d: bad shape");
@@ -1163,7 +1306,12 @@ extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t
             if (q->partial_floats > part) part = q->partial_floats;
         }
     }
-    return (packed + part) * (int64_t)sizeof(float);
+    int64_t bytes = (packed + part) * (int64_t)sizeof(float);
+    if (per_image_weights && k == 1) {                      // packed bf16x6 head weights (head_split_kernel)
+        const int64_t hb = head_packed_units(n, cdiv(cin, 16), 3, cout <= 32 ? 1 : 6) * 16;
+        if (hb > bytes) bytes = hb;
+    }
+    return bytes;
 }
 
 extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
@@ -1174,6 +1322,22 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     int rc = check_modconv(p);
     if (rc) return rc;
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
+    hipStream_t st_head = (hipStream_t)stream;
+    if (head_split_applies(p, resolve_arith(p.arith))) {
+        const int parts = resolve_arith(p.arith) == 3 ? 2 : 3, mt = p.cout <= 32 ? 1 : 6, cchunks = cdiv(p.cin, 16);
+        IDE3D_CHECK_ARG(p.workspace_bytes >= head_packed_units(p.n, cchunks, parts, mt) * 16, "modconv2d: workspace too small for the packed head weights");
+        u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
+        const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
+        const int tiles = cdiv(p.h * p.w_, 128);
+#define IDE3D_HEAD(P, M) do { \
+            hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
+            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(256), 0, st_head, p, wu, cchunks, tiles); } while (0)
+        if (parts == 2) { if (mt == 1) IDE3D_HEAD(2, 1); else IDE3D_HEAD(2, 6); }
+        else            { if (mt == 1) IDE3D_HEAD(3, 1); else IDE3D_HEAD(3, 6); }
+#undef IDE3D_HEAD
+        IDE3D_CHECK_LAUNCH("modconv2d (split-bf16 heads)");
+        return IDE3D_OK;
+    }
     ConvPlan pl; plan_conv(p, pl, resolve_arith(p.arith));
     IDE3D_CHECK_ARG(p.workspace_bytes >= (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float),
                     "modconv2d: workspace too small (need %lld bytes)", (long long)((pl.packed_floats + pl.partial_floats) * sizeof(float)));

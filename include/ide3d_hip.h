@@ -367,6 +367,7 @@ int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
  *   3  bf16x3: 2 pieces, 3 products, per-product error ~2^-17 relative, 3/16 of the time;
  *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3, else bf16x6 (measured against a
  *      float64 convolution its error equals the fp32 MFMA's: max 1.3e-6 vs 1.4e-6 of max |y| at 128 -> 128 @256).
+ * The same switch selects the arithmetic of per-image 1x1 heads with <= 32 or 161..192 outputs on grids of >= 512 workgroups.
  * Packed weights in a modconv workspace are specific to the arithmetic they were packed for.
  */
 int     ide3d_set_conv_arithmetic(int32_t arith);

@@ -176,3 +176,20 @@ def test_graphed_renderer_is_deterministic_with_split_arithmetic(gpu_device):
             assert torch.equal(img, img_e) and torch.equal(seg, seg_e)
     finally:
         hip_plugin.conv_arithmetic('default')
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 22, 200, 180), (4, 128, 192, 128, 130), (1, 100, 19, 255, 257), (2, 256, 192, 32, 32)], ids=lambda s: 'x'.join(map(str, s)))
+def test_per_image_heads_vs_float64(gpu_device, shape):
+    """The dual toRGB + toSeg heads (per-image folded 1x1 weights, bias, clamp) on the split-bf16 head kernel (>= 512 workgroups of 128 pixels, <= 32 or
+    161..192 outputs; the last shape stays on the fp32 loop) against a float64 einsum; ragged pixel counts and a channel count that is no multiple of 16."""
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, cin, h, w, generator=g).to(gpu_device)
+    wt = (torch.randn(n, cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(gpu_device)
+    bias = torch.randn(cout, generator=g).to(gpu_device)
+    ref = (torch.einsum('noc,nchw->nohw', wt[:, :, :, 0, 0].double(), x.double()) + bias.double()[None, :, None, None]).clamp(-2.0, 2.0)
+    assert float((ref.abs() == 2.0).float().mean()) > 1e-4, 'the clamp must be active'
+    for name, code in ARITH.items():
+        y = _mc()(x, wt, None, None, None, 0.0, bias, 1, 0.0, 1.0, 2.0, arith=code).double()
+        err = float((y - ref).abs().max() / ref.abs().max())
+        assert err < TOL[name], f'{name}: {err:.3e}'
