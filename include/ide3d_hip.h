@@ -327,8 +327,8 @@ int ide3d_density_lattice(const ide3d_render_params* p, const ide3d_lattice* lat
  * x [n, cin, h, w], y [n, cout, h, w] NCHW contiguous float32; w [cout, cin, k, k];
  * styles s [n, cin]; dcoefs d [n, cout] or NULL (no demodulation); noise [h, w] or NULL;
  * bias [cout] or NULL.  act: 1 linear, 3 lrelu (bias_act cuda_idx).  k in {1, 3}.
- * fp32 in / fp32 out / fp32 accumulate.  1x1, per-image-weight, stride-2 and narrow (< 64 output channels, < 12 pixels) layers run
- * on v_mfma_f32_32x32x2_f32 (exact fp32 products); the shared-weight 3x3 and transposed 3x3 layers run in the arithmetic
+ * fp32 in / fp32 out / fp32 accumulate.  Shared-weight 1x1, stride-2, narrow (< 64 output channels, <= 32 input channels) and small
+ * (< 12 pixels) layers run on v_mfma_f32_32x32x2_f32 (exact fp32 products); the shared-weight 3x3 and transposed 3x3 layers run in the arithmetic
  * selected by `arith` / ide3d_set_conv_arithmetic() below.
  */
 typedef struct ide3d_modconv_params {
