@@ -815,13 +815,16 @@ class StylePlugin:
 
 class FramePlugin:
     @staticmethod
-    def frame_u8(img, seg, palette):
+    def frame_u8(img, seg, palette, out=None):
         img, seg = img.contiguous(), seg.contiguous()
         _require(img.is_cuda and img.dtype == torch.float32 and seg.dtype == torch.float32, 'frame_u8: float32 CUDA tensors required')
         n, _, H, W = img.shape
         classes = seg.shape[1]
         _require(palette.dtype == torch.uint8 and palette.shape == (classes, 3) and palette.is_cuda, 'palette must be uint8 [classes, 3] on GPU')
-        out = torch.empty([n, H, 2 * W, 3], dtype=torch.uint8, device=img.device)
+        if out is None:
+            out = torch.empty([n, H, 2 * W, 3], dtype=torch.uint8, device=img.device)
+        _require(out.dtype == torch.uint8 and tuple(out.shape) == (n, H, 2 * W, 3) and out.is_contiguous() and out.device == img.device,
+                 'frame_u8: out must be a contiguous uint8 [N, H, 2W, 3] tensor on the image device')
         with torch.cuda.device(img.device):
             rc = load().ide3d_frame_u8(_ptr(img), _ptr(seg), _ptr(palette.contiguous()), n, classes, H, W, _ptr(out), _stream(img))
         _check(rc, 'frame_u8')

@@ -34,18 +34,69 @@ def palette_tensor(num_classes, device):
     return torch.tensor(pal, dtype=torch.uint8, device=device)
 
 
-def frames_u8(img, seg, palette=None):
-    """[N, 3, H, W] image in [-1, 1] + [N, K, H, W] logits -> uint8 [N, H, 2W, 3] (RGB | palette[argmax seg])."""
+def frames_u8(img, seg, palette=None, out=None):
+    """[N, 3, H, W] image in [-1, 1] + [N, K, H, W] logits -> uint8 [N, H, 2W, 3] (RGB | palette[argmax seg]).
+    `out`: write into this (contiguous, same shape) tensor instead of a new one — the send buffers of `OverlappedFrameGather`."""
     global _frame_plugin
     if palette is None:
         palette = palette_tensor(seg.shape[1], img.device)
     if img.device.type == 'cuda' and img.dtype == torch.float32 and img.shape[-1] % 4 == 0:
         if _frame_plugin is None:
             _frame_plugin = custom_ops.get_plugin(module_name='frame_plugin', sources=['frame.hip'])
-        return _frame_plugin.frame_u8(img, seg.float(), palette)
+        return _frame_plugin.frame_u8(img, seg.float(), palette, out=out)
     rgb = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
     col = palette[torch.argmax(seg, dim=1)]
+    if out is not None:
+        return torch.cat([rgb, col], dim=2, out=out)
     return torch.cat([rgb, col], dim=2).contiguous()
+
+
+class OverlappedFrameGather:
+    """Double-buffered, asynchronous gather of fixed-size uint8 frame batches to rank `dst` ("gather of batch k
+    overlaps render of k+1").  Step k writes its frames into `slot()` — a send buffer whose previous gather (step k - depth) has been
+    waited for — and `submit()`s it: `dist.gather(..., async_op=True)` runs on the communication stream (RCCL's own stream; a gloo
+    worker thread on CPU), so the compute stream goes straight on to step k + 1.  Only the wait in `slot()` / `drain()` orders the two
+    streams again.  On `dst`, `received(i)` is the list of per-rank buffers of submission i (valid after `drain()` or after the
+    matching `wait(i)`); a buffer is reused `depth` submissions later.  Nothing like it upstream: the reference renders on one GPU."""
+
+    def __init__(self, shape, device, rank, world, dst=0, depth=2, dtype=torch.uint8):
+        import torch.distributed as dist
+        self._dist, self.rank, self.world, self.dst, self.depth = dist, rank, world, dst, depth
+        self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(world)] if rank == dst else None for _ in range(depth)]
+        self.work = [None] * depth
+        self.submitted = 0
+
+    def wait(self, i):
+        """Wait (stream-ordered on the GPU) for submission number i, if it is still in flight."""
+        b = i % self.depth
+        if self.work[b] is not None and self.submitted - i <= self.depth:
+            self.work[b].wait()
+            self.work[b] = None
+
+    def slot(self):
+        """The send buffer of the next submission; its previous use has completed when this returns."""
+        b = self.submitted % self.depth
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        return self.send[b]
+
+    def submit(self):
+        """Start the gather of the buffer `slot()` returned; returns the submission number."""
+        b = self.submitted % self.depth
+        self.work[b] = self._dist.gather(self.send[b], self.recv[b], dst=self.dst, async_op=True)
+        self.submitted += 1
+        return self.submitted - 1
+
+    def received(self, i):
+        return self.recv[i % self.depth]
+
+    def drain(self):
+        for b in range(self.depth):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
 
 
 def shard_items(num_seeds: int, num_poses: int, rank: int, world: int) -> List[Tuple[int, int]]:

@@ -99,6 +99,43 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // producer / consumer kernel (round 3): stamps of wave 0 of each role of one workgroup, per iteration
+        if (dbg_fn dbgp = (dbg_fn)dlsym(lib, "ide3d_debug_tt_pc")) {
+            static unsigned long long v[3][32][8];
+            if (dbgp(&v[0][0][0]) == 0 && v[0][1][0]) {
+                printf("  pc iteration: T [tap table, taps + coords, exchange + regions, barrier wait] total | F [issue, commit, barrier wait] total | B [blend, barrier wait] total\n");
+                for (int it = 0; it < 24; ++it) {
+                    const unsigned long long *t = v[0][it], *f = v[1][it], *b = v[2][it];
+                    if (!t[0]) continue;
+                    printf("  %2d:", it);
+                    for (int i = 0; i < 4; ++i) printf(" %6lld", (long long)(t[i + 1] - t[i]));
+                    printf("  total %6lld |", (long long)(t[4] - t[0]));
+                    for (int i = 0; i < 3; ++i) printf(" %6lld", (long long)(f[i + 1] - f[i]));
+                    printf("  total %6lld |", (long long)(f[3] - f[0]));
+                    for (int i = 0; i < 2; ++i) printf(" %6lld", (long long)(b[i + 1] - b[i]));
+                    printf("  total %6lld\n", (long long)(b[2] - b[0]));
+                }
+            }
+        }
+        if (dbg_fn dbgw = (dbg_fn)dlsym(lib, "ide3d_debug_tt_wg")) {
+            static unsigned long long w[1024][4];
+            if (dbgw(&w[0][0]) == 0 && w[0][0]) {
+                unsigned long long cmin = ~0ull, cmax = 0, csum = 0, r0 = ~0ull, r1 = 0, part = 0; int nw = 0;
+                for (int i = 0; i < 1024 && w[i][0]; ++i, ++nw) {
+                    cmin = std::min(cmin, w[i][0]); cmax = std::max(cmax, w[i][0]); csum += w[i][0];
+                    r0 = std::min(r0, w[i][1]); r1 = std::max(r1, w[i][2]); part += w[i][3] >> 32;
+                }
+                printf("  per workgroup (%d): cycles min %llu avg %llu max %llu; first entry -> last end %.2f us (100 MHz clock); chunks with a plane not staged: %llu\n",
+                       nw, cmin, csum / nw, cmax, (double)(r1 - r0) / 100.0, part);
+                // histogram of workgroup durations and of start skew
+                int hist[8] = {0}; double skew_max = 0;
+                for (int i = 0; i < nw; ++i) { int b = (int)((w[i][0] - cmin) * 8 / (cmax - cmin + 1)); hist[b]++; skew_max = std::max(skew_max, (double)(w[i][1] - r0) / 100.0); }
+                printf("  duration histogram (8 bins min..max):"); for (int b = 0; b < 8; ++b) printf(" %d", hist[b]); printf("; latest start +%.2f us\n", skew_max);
+                printf("  slowest workgroups:"); 
+                for (int k = 0; k < 8; ++k) { int bi = 0; for (int i = 0; i < nw; ++i) if (w[i][0] > w[bi][0]) bi = i; printf(" %d:%llu(np %llu)", bi, w[bi][0], w[bi][3] >> 32); w[bi][0] = 1; }
+                printf("\n");
+            }
+        }
         // keep the library mapped (its kernels are registered with the runtime)
     }
     return 0;
