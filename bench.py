@@ -44,7 +44,7 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY = 6.29e12           # B/s, measured copy ceiling (same guide)
 FP32_MFMA_PEAK = 157.3e12    # FLOP/s
 BATCH = 4                    # seeds per rank per step (BASELINE config 2)
-PROFILE_ROUND = 'round2'
+PROFILE_ROUND = 'round3'
 YAWS = (-0.5, 0.0, 0.5, 0.25)
 PARITY_JITTER_SEED = 11      # = oracle/make_bench_parity.py
 
@@ -135,15 +135,20 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
     algo = gather_bytes(n)
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
     # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
-    traffic = None
-    for rnd in (PROFILE_ROUND, 'round1'):
+    traffic, traffic_source = None, None
+    for rnd in (PROFILE_ROUND, 'round2', 'round1'):
         pmc = os.path.join(ROOT, 'profiles', rnd, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
         if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get('hbm_traffic_bytes_per_launch')
+            rec = json.load(open(pmc))
+            traffic = rec.get('hbm_traffic_bytes_per_launch')
+            traffic_source = (f'profiles/{rnd}/{os.path.basename(pmc)} (kernel {rec.get("kernel", "?")}): rocprofv3 --pmc passes of this launch shape, '
+                              'committed; NOT measured in this run')
             break
     rate = algo / (avg * 1e-3)
-    return dict(kernel='triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel', bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9,
-                unit='GB/s', frac=rate / HBM_PEAK, frac_of_measured_copy_ceiling=rate / HBM_COPY, traffic=traffic, bytes_per_launch=algo,
+    kernel = 'triplane_sample_tile_pc_kernel' if tiled and os.environ.get('IDE3D_GATHER_PC', '8') != '0' else \
+             'triplane_sample_tile_kernel' if tiled else 'triplane_sample_cl2_kernel'
+    return dict(kernel=kernel, bound='hbm', achieved=rate / 1e9, peak=HBM_PEAK / 1e9,
+                unit='GB/s', frac=rate / HBM_PEAK, frac_of_measured_copy_ceiling=rate / HBM_COPY, traffic=traffic, traffic_source=traffic_source, bytes_per_launch=algo,
                 avg_launch_us=avg * 1e3, min_launch_us=ms[0] * 1e3, median_launch_us=ms[len(ms) // 2] * 1e3,
                 timed_launches=iters, warm_launches=warm_launches,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
@@ -250,6 +255,7 @@ def main():
     ap.add_argument('--conv-arith', default='default', choices=['default', 'fp32', 'bf16x6', 'bf16x3'],
                     help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h); default = the library default')
     ap.add_argument('--no-arith-sweep', action='store_true', help='skip the short runs with the other conv arithmetics (N = 1 only)')
+    ap.add_argument('--blocking-gather', action='store_true', help='N > 1: synchronous gather on the compute stream in the timed steps')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='launcher / protocol self-test without a GPU: tiny generator on CPU tensors, gloo backend (tests/test_bench_launcher_cpu.py)')
     args = ap.parse_args()
@@ -310,13 +316,11 @@ def main():
     palette = dr.palette_tensor(spec.seg_channels, device)
     gathered = [torch.empty([BATCH, res, 2 * res, 3], dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
 
+    # The headline is the hipGraph replay.  A failed capture is an error (exit code != 0, no JSON line) unless eager launches were
+    # asked for with --graph 0: a silently slower eager number must never stand in for the graph's.
     graphed = None
     if args.graph and not cpu:
-        try:
-            graphed = triplane.GraphedRenderer(G, BATCH, device)
-        except Exception as e:      # capture is an optimisation, never a requirement
-            print(f'[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
-            graphed = None
+        graphed = triplane.GraphedRenderer(G, BATCH, device)
 
     def render(z, c_cond, c_cam, jitter=None):
         """The benchmarked callable: new latents (and fresh stratified jitter unless given) -> (img, seg)."""
@@ -326,30 +330,42 @@ def main():
             ws = G.mapping(z.float(), c_cond)
             return G.synthesis(ws, c=c_cam, noise_mode='const', return_seg=True, ray_jitter=jitter)
 
-    def step(i):
-        seeds = [(i * world + rank) * BATCH + j for j in range(BATCH)]
-        z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(spec.z_dim) for s in seeds])).to(device)
-        img, seg = render(z, cond, cams)
+    # N > 1: the uint8 frames of step k travel to rank 0 (RCCL gather, 7 concurrent peer -> root xGMI copies) WHILE step k + 1 renders:
+    # double-buffered send / receive tensors, `dist.gather(async_op=True)` on the communication stream (dr.OverlappedFrameGather).
+    # `--blocking-gather` restores the synchronous gather on the compute stream (measured next to it as `ms_per_step_blocking_gather`).
+    og = dr.OverlappedFrameGather([BATCH, res, 2 * res, 3], device, rank, world) if dist else None
+
+    def latents(i, r=None):
+        seeds = [(i * world + (rank if r is None else r)) * BATCH + j for j in range(BATCH)]
+        return torch.from_numpy(np.stack([np.random.RandomState(s).randn(spec.z_dim) for s in seeds])).to(device)
+
+    def step(i, blocking=False, jitter=None):
+        img, seg = render(latents(i), cond, cams, jitter)
         with torch.no_grad():
-            frames = dr.frames_u8(img, seg, palette)
-        if dist:
-            dist.gather(frames, gathered, dst=0)
+            if dist and not blocking:
+                frames = dr.frames_u8(img, seg, palette, out=og.slot())
+                og.submit()
+            else:
+                frames = dr.frames_u8(img, seg, palette)
+                if dist:
+                    dist.gather(frames, gathered, dst=0)
         return frames
 
     def barrier():
         if dist:
+            og.drain()
             dist.barrier()
         sync()
 
     for i in range(args.warmup):
-        step(i)
+        step(i, blocking=args.blocking_gather)
     block_s, rank_s = [], []
     done = args.warmup
     for _b in range(max(1, args.blocks)):
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(done + i)
+            step(done + i, blocking=args.blocking_gather)
         barrier()
         dt = time.perf_counter() - t0
         done += args.steps
@@ -361,26 +377,61 @@ def main():
         block_s.append(dt); rank_s.append(mine)
 
     # N > 1 extras: per-rank frame rates (own clock, median block) and the cost of the RCCL gather alone
-    per_rank, gather_ms = None, None
+    per_rank, gather_ms, blocking_ms, gather_check = None, None, None, None
     if dist:
         mine = torch.tensor([BATCH * args.steps / sorted(rank_s)[len(rank_s) // 2]], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(t) for t in allr]
-        frames = step(done); done += 1
+        # the same K steps with the gather synchronous on the compute stream (what round 2 timed), for comparison
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(done + i, blocking=True)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        blocking_ms = float(tt) / args.steps * 1e3
+        done += args.steps
+        # the gather alone
+        frames = step(done, blocking=True); done += 1
         barrier()
         t0 = time.perf_counter()
         for _ in range(5):
             dist.gather(frames, gathered, dst=0)
         barrier()
         gather_ms = (time.perf_counter() - t0) / 5 * 1e3
+        # contents and order through the double buffer: three overlapped steps with fixed jitter; rank 0 renders every rank's frames
+        # itself and compares them with what arrived (byte-equal: same weights, same inputs, same kernels on every rank)
+        jit_fix = torch.rand(BATCH, spec.render_size ** 2, spec.num_steps, generator=torch.Generator().manual_seed(PARITY_JITTER_SEED)).to(device)
+        subs = []
+        for k in range(3):
+            step(done + k, jitter=jit_fix)
+            subs.append(og.submitted - 1)
+            if rank == 0 and k >= 1:           # read submission k - 1 while k is in flight (its buffers are not reused before k + 1)
+                og.wait(subs[k - 1]); sync()
+                subs[k - 1] = [t.clone() for t in og.received(subs[k - 1])]
+        barrier()
+        if rank == 0:
+            subs[2] = [t.clone() for t in og.received(subs[2])]
+            bad = 0
+            for k in range(3):
+                for r in range(world):
+                    img, seg = render(latents(done + k, r), cond, cams, jit_fix)
+                    with torch.no_grad():
+                        want = dr.frames_u8(img, seg, palette)
+                    bad += int((subs[k][r] != want).any())
+            gather_check = {'ok': bad == 0, 'steps': 3, 'ranks': world, 'mismatching_buffers': bad,
+                            'what': 'frames received through the double-buffered async gather == frames rank 0 renders for the same (step, rank) inputs'}
+        done += 3
 
     if rank == 0:
         order = sorted(block_s)
         med = order[len(order) // 2]
         frames_block = BATCH * world * args.steps
         out = {
-            'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': frames_block / med, 'unit': 'frames/s',
+            'metric': f'512x512 RGB+seg frames/s @96 depth samples (whole job; 3x3 convolutions in {arith})', 'value': frames_block / med, 'unit': 'frames/s',
+            'value_fp32_exact': (frames_block / med) if arith == 'fp32' else None,     # filled from the fp32 leg of the arithmetic sweep below
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH_DTYPE[arith], 'data': 'synthetic',
             'config': {'workload': 'gen_images.py-style: random-init ide3d-ffhq-64-512, G.mapping + G.synthesis (64 neural render -> 512, '
@@ -399,6 +450,10 @@ def main():
             out['rccl_ranks'] = world
             out['frames_per_s_by_rank'] = per_rank
             out['gather_ms'] = gather_ms
+            out['gather_overlap'] = {'mode': 'async, double-buffered (gather of step k on the communication stream while step k + 1 renders)',
+                                     'ms_per_step_overlapped': med / args.steps * 1e3, 'ms_per_step_blocking_gather': blocking_ms,
+                                     'gather_ms_alone': gather_ms}
+            out['gather_check'] = gather_check
             out['gather_bytes_per_rank_per_step'] = BATCH * res * 2 * res * 3
         if cpu:
             out['metric'] = 'DRY RUN (CPU tensors, tiny generator, gloo): launcher / protocol self-test, not a measurement'
@@ -439,6 +494,8 @@ def main():
                     graphed = keep
                     hip_plugin.conv_arithmetic(args.conv_arith)
             out['by_conv_arithmetic'] = sweep
+            out['value_fp32_exact'] = sweep['fp32']['frames_per_s']       # exact-fp32 products (v_mfma_f32_32x32x2_f32) in every convolution
+            out['value_fp32_exact_parity_ok'] = sweep['fp32'].get('parity_ok')
         if not cpu and not args.no_roofline:
             out['roofline'] = bench_gather(device)
         if not cpu and world == 1 and not args.no_roofline_extra:

@@ -29,6 +29,19 @@ def test_launch_ranks_function_two_gloo_ranks():
     assert rec['gather_ms'] > 0 and rec['timing']['blocks'] == 3
     assert rec['timing']['ms_per_step_min'] <= rec['ms_per_step'] <= rec['timing']['ms_per_step_max']
     assert 'DRY RUN' in rec['metric']
+    # the double-buffered asynchronous gather: contents and order checked by rank 0 against its own render of every rank's inputs
+    assert rec['gather_check']['ok'] is True and rec['gather_check']['steps'] == 3 and rec['gather_check']['ranks'] == 2
+    ov = rec['gather_overlap']
+    assert ov['ms_per_step_overlapped'] > 0 and ov['ms_per_step_blocking_gather'] > 0 and ov['gather_ms_alone'] > 0
+
+
+def test_blocking_gather_flag_two_gloo_ranks():
+    sys.path.insert(0, ROOT)
+    import bench
+    rc, out = bench.launch_ranks(2, ['--gpus', '2', '--blocking-gather'] + ARGS, capture=True)
+    assert rc == 0
+    rec = _one_json_line(out)
+    assert rec['n_gpus'] == 2 and rec['gather_check']['ok'] is True
 
 
 def test_plain_invocation_self_launches():

@@ -85,3 +85,37 @@ def test_frames_u8_cpu_matches_oracle():
     img = torch.randn(2, 3, 8, 12, generator=g); seg = torch.randn(2, 19, 8, 12, generator=g)
     assert np.array_equal(dr.frames_u8(img, seg).numpy(), oracle_ops.frame_u8(img, seg))
     assert np.array_equal(np.array(dr.PALETTE, dtype=np.uint8), oracle_ops.PALETTE)
+
+
+def _overlap_worker(rank, world, port, out_path):
+    for p in (os.path.join(ROOT, 'ide-3d_amd'), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from training import distributed_render as dr
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    og = dr.OverlappedFrameGather([2, 4, 8, 3], torch.device('cpu'), rank, world, depth=2)
+    seen = []
+    for step in range(5):                          # more submissions than buffers: every buffer is reused at least once
+        og.slot().fill_(step * 10 + rank)          # slot() has waited for the buffer's previous gather
+        i = og.submit()
+        assert i == step
+        if rank == 0 and step >= 1:                # read step - 1 while step is in flight
+            og.wait(step - 1)
+            seen.append([int(t.unique().item()) for t in og.received(step - 1)])
+    og.drain()
+    if rank == 0:
+        seen.append([int(t.unique().item()) for t in og.received(4)])
+        np.save(out_path, np.array(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_frame_gather_order_and_contents(tmp_path):
+    """The double-buffered asynchronous gather bench.py's N > 1 step uses: submission i delivers rank r's buffer of step i, in order,
+    also when a buffer is on its second and third use."""
+    out = str(tmp_path / 'seen.npy')
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [[s * 10, s * 10 + 1] for s in range(5)]
