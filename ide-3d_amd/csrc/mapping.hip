@@ -13,7 +13,8 @@
 // One kernel, MAP_WGS workgroups of 256 threads: every workgroup keeps the current activation vector of all images in LDS
 // and computes a slice of each layer's outputs (a wave = a few rows, lanes split K with 16-byte loads, all rows of a 256-column
 // slab requested before any is used: the GEMV is latency-bound); the new activations go through a global buffer and a
-// grid-wide barrier (monotonic atomic counter — all MAP_WGS workgroups are co-resident: 64 << 256 CUs x occupancy).
+// grid-wide barrier (monotonic atomic counter; all MAP_WGS = 64 workgroups must be co-resident: checked against the occupancy query
+// on the host, and the spin is bounded).
 #include "common.h"
 
 namespace ide3d {
@@ -39,13 +40,26 @@ struct MapArgs {
     int cutoff;                                             // layers [0, cutoff) are truncated (num_ws = all)
 };
 
+// Grid-wide barrier on one monotonic counter, in the form MI355X_MICROARCH.md prescribes for inter-workgroup hand-offs (per-XCD L2s
+// are not coherent and a CU's L1 is never refreshed by other CUs' stores): plain payload stores -> __syncthreads -> lane 0: agent-scope
+// RELEASE fence (L2 write-back) + explicit vmcnt(0) (hipcc may drop the fence's own wait) -> relaxed arrive; RELAXED polling with
+// s_sleep (an acquire per poll would invalidate this CU's L1 every iteration) -> ONE agent-scope ACQUIRE fence -> __syncthreads.
+// The spin is bounded: all MAP_WGS workgroups must be co-resident for the barrier to complete (checked on the host against the
+// occupancy query, `mapping_resident`), and should that ever fail — a CU mask, a foreign kernel pinning the LDS — the kernel traps after
+// ~2^22 polls (seconds) with the error word set: a reported launch failure, also inside a hipGraph replay, instead of a hung GPU.
+constexpr unsigned MAP_SPIN_LIMIT = 1u << 22;
 __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(counter, 1u);
-        while (__atomic_load_n(counter, __ATOMIC_ACQUIRE) < target) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > MAP_SPIN_LIMIT) { __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_trap(); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -172,8 +186,24 @@ extern "C" int ide3d_mapping_workspace_bytes(void) {
     return (int)(ide3d::MAP_MAX_LAYERS * ide3d::MAP_MAX_N * ide3d::MAP_MAX_K * sizeof(float) + 256);
 }
 
+// 1 if MAP_WGS workgroups of the mapping kernel are co-resident on the current device with a 2x margin (the occupancy API can be one
+// block per CU high on gfx950 — MI355X_MICROARCH.md "Residency and cooperative launch" — and other kernels may hold part of the chip).
+static bool mapping_resident() {
+    static const int ok = [] {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ide3d::mapping_kernel, 256, 0) != hipSuccess) return 0;
+        if (per_cu > 1) per_cu -= 1;                                       // the API's possible overcount
+        return ((int64_t)per_cu * prop.multiProcessorCount >= 2 * ide3d::MAP_WGS) ? 1 : 0;
+    }();
+    return ok != 0;
+}
+extern "C" int ide3d_mapping_supported(void) { return mapping_resident() ? 1 : 0; }
+
 extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
     using namespace ide3d;
+    if (!mapping_resident()) { set_error("mapping: %d workgroups cannot be co-resident on this device (grid barrier)", MAP_WGS); return IDE3D_ENOKERNEL; }
     IDE3D_CHECK_ARG(q != nullptr, "mapping: null params");
     IDE3D_CHECK_ARG(q->n > 0 && q->n <= MAP_MAX_N, "mapping: batch must be 1..%d (got %d)", MAP_MAX_N, q->n);
     IDE3D_CHECK_ARG(q->layers >= 1 && q->layers <= MAP_MAX_LAYERS, "mapping: 1..%d layers", MAP_MAX_LAYERS);
@@ -201,7 +231,7 @@ extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
     a.alpha = q->alpha; a.act_gain = q->act_gain; a.psi = q->truncation_psi;
     a.cutoff = (q->truncation_cutoff < 0) ? q->num_ws : q->truncation_cutoff;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.counter, 0, sizeof(unsigned), st) != hipSuccess) { set_error("mapping: hipMemsetAsync failed"); return IDE3D_ELAUNCH; }
+    if (hipMemsetAsync(a.counter, 0, 2 * sizeof(unsigned), st) != hipSuccess) { set_error("mapping: hipMemsetAsync failed"); return IDE3D_ELAUNCH; }
     hipLaunchKernelGGL(mapping_kernel, dim3(MAP_WGS), dim3(256), 0, st, a);
     IDE3D_CHECK_LAUNCH("mapping");
     return IDE3D_OK;

@@ -190,27 +190,36 @@ def open_url(url: str, cache_dir: str = None, num_attempts: int = 10, verbose: b
     return ref.open_url(url, cache_dir=cache_dir, num_attempts=num_attempts, verbose=verbose, return_filename=return_filename, cache=cache)
 
 
-_ref_util = False
+_ref_util = False          # False = not looked for yet; None = no reference checkout behind the overlay; else the loaded module
+_ref_util_error = None     # the exception of a failed load (cached: the outcome must not depend on how often / in which order it is asked for)
 
 
 def _reference_util():
     """The reference's own dnnlib/util.py, when a reference checkout sits behind this overlay on sys.path (the overlay package
-    extends its __path__ over it), loaded under a private name; None otherwise."""
-    global _ref_util
+    extends its __path__ over it), loaded under a private name; None otherwise.  A reference file that is present but cannot be
+    imported (it imports `requests` etc. at module level) raises ImportError — every time, with the original cause chained."""
+    global _ref_util, _ref_util_error
+    if _ref_util_error is not None:
+        raise ImportError(f"the reference's dnnlib/util.py behind the overlay could not be imported: {_ref_util_error!r}") from _ref_util_error
     if _ref_util is False:
-        _ref_util = None
         import os
         import importlib.util
         import dnnlib
+        found = None
         here = os.path.dirname(os.path.abspath(__file__))
         for d in list(dnnlib.__path__):
             cand = os.path.join(d, 'util.py')
             if os.path.abspath(d) != here and os.path.isfile(cand):
                 spec = importlib.util.spec_from_file_location('dnnlib._reference_util', cand)
                 mod = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(mod)
-                _ref_util = mod
+                try:
+                    spec.loader.exec_module(mod)
+                except Exception as e:      # noqa: BLE001 - whatever the foreign module raises while importing
+                    _ref_util_error = e
+                    raise ImportError(f"the reference's dnnlib/util.py ({cand}) could not be imported: {e!r}") from e
+                found = mod
                 break
+        _ref_util = found
     return _ref_util
 
 
@@ -218,7 +227,11 @@ def __getattr__(name: str) -> Any:
     """Helpers this overlay does not re-state (Logger, format_time, make_cache_dir_path, ...) come from the reference's util."""
     if name.startswith('__'):
         raise AttributeError(name)
-    ref = _reference_util()
+    try:
+        ref = _reference_util()
+    except ImportError as e:
+        # module __getattr__ must answer AttributeError (hasattr / getattr-with-default rely on it); the cause stays attached
+        raise AttributeError(f"module 'dnnlib.util' has no attribute {name!r} (and the reference's util.py behind the overlay failed to import)") from e
     if ref is not None and hasattr(ref, name):
         return getattr(ref, name)
     raise AttributeError(f"module 'dnnlib.util' has no attribute {name!r}")

@@ -204,6 +204,7 @@ def load():
             'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
             'ide3d_mapping': [ctypes.POINTER(_MappingParams), vp],
             'ide3d_mapping_workspace_bytes': [],
+            'ide3d_mapping_supported': [],
             'ide3d_skip_upsample_add_cl': [vp, ctypes.POINTER(i64 * 4), vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, vp],
             'ide3d_bilinear_up2_split': [vp, i32, i32, i32, i32, ctypes.POINTER(vp * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(i32 * 3), vp],
         }
@@ -221,7 +222,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
-    'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes',
+    'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
 )
 
 
@@ -235,6 +236,48 @@ def _check(rc, what):
 
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---- who owns a launch's scratch memory ------------------------------------------------------------------------------------------
+# Split-K partials, packed weights and the mapping kernel's barrier counter live in workspaces that belong to ONE launch at a time.
+# Eager callers are told apart by their stream (two streams never share a workspace).  A stream HANDLE is not an identity, though:
+# PyTorch hands pooled handles out round-robin and a hipGraph is replayed on whatever stream is current, so a captured graph owns its
+# workspaces through `workspace_scope(owner)` instead: everything launched inside the scope is keyed by the owner object (one
+# `GraphedRenderer`), and the entries are dropped when the owner is garbage-collected.  Two graphs therefore never share scratch
+# memory with each other or with eager callers; replays of ONE graph must be serialised (they share its static buffers anyway).
+_scope = threading.local()
+_scope_finalizers = {}
+
+
+def _drop_owner(domain):
+    _scope_finalizers.pop(domain, None)
+    for cache in (ModconvPlugin._ws, MappingPlugin._ws):
+        for k in [k for k in cache if domain in k]:
+            del cache[k]
+
+
+class workspace_scope:
+    """`with workspace_scope(owner): ...` — launches inside use workspaces owned by `owner` (any weak-referenceable object)."""
+
+    def __init__(self, owner):
+        self.domain = ('owner', id(owner))
+        if self.domain not in _scope_finalizers:
+            _scope_finalizers[self.domain] = weakref.finalize(owner, _drop_owner, self.domain)
+
+    def __enter__(self):
+        self.prev = getattr(_scope, 'domain', None)
+        _scope.domain = self.domain
+        return self
+
+    def __exit__(self, *exc):
+        _scope.domain = self.prev
+        return False
+
+
+def _ws_domain(device):
+    """Key component that separates workspaces of concurrent launch sequences: the owner of the active scope, else the current stream."""
+    dom = getattr(_scope, 'domain', None)
+    return dom if dom is not None else ('stream', torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -714,12 +757,11 @@ class ModconvPlugin:
         oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (((h - 3) // 2 + 1, (wd - 3) // 2 + 1) if mode == 1 else (h, wd))
         y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
         lib = load()
-        # one workspace per (weight, problem shape, device, stream): the split-K partials inside it belong to one launch at a
-        # time, and launches on different streams (a graph replay next to an eager call) must not share them
+        # one workspace per (weight, problem shape, device, launch domain): the split-K partials inside it belong to one launch at a
+        # time; the domain is the current stream for eager callers and the owning GraphedRenderer inside `workspace_scope`
         # ... and per arithmetic: the packed weights of the split-bf16 loops differ from the fp32 loop's
         arith = int(arith) or int(lib.ide3d_get_conv_arithmetic())
-        key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index,
-               torch.cuda.current_stream(x.device).cuda_stream, arith)
+        key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index, _ws_domain(x.device), arith)
         ent = ModconvPlugin._ws.get(key)
         if ent is None:
             nbytes = lib.ide3d_modconv_workspace_bytes(n, cin, cout, h, wd, k, mode, int(per_image))
@@ -833,13 +875,14 @@ class FramePlugin:
 
 class MappingPlugin:
     MAX_N, MAX_WIDTH, MAX_LAYERS = 8, 1024, 16
-    _ws = {}          # (device index, stream) -> workspace tensor (activation ping-pong + barrier counter), never freed
+    _ws = {}          # (device index, launch domain) -> workspace tensor (per-layer activations + barrier counter); see workspace_scope
 
     @staticmethod
     def supports(n, z_dim, embed, widths):
         k0 = z_dim + embed
         return (1 <= n <= MappingPlugin.MAX_N and 0 < k0 <= MappingPlugin.MAX_WIDTH and k0 % 4 == 0 and 1 <= len(widths) <= MappingPlugin.MAX_LAYERS
-                and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths))
+                and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths)
+                and bool(load().ide3d_mapping_supported()))      # the kernel's grid barrier needs its 64 workgroups co-resident
 
     @staticmethod
     def mapping(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff):
@@ -850,12 +893,19 @@ class MappingPlugin:
         n, z_dim = z.shape
         embed = 0 if embed_w is None else embed_w.shape[0]
         _require(MappingPlugin.supports(n, z_dim, embed, [w.shape[0] for w in fc_ws]), 'mapping: unsupported shape')
+        # the kernel indexes c as [n, c_dim] and w_avg as [w_dim]: a smaller conditioning batch (torch.cat would raise in the
+        # reference, networks.py:302) or a short w_avg must not become an out-of-bounds read
+        _require((embed_w is None) or (c is not None and embed_w.ndim == 2 and tuple(c.shape) == (n, embed_w.shape[1])),
+                 f'mapping: c must be [{n}, {None if embed_w is None else embed_w.shape[1]}] (got {None if c is None else tuple(c.shape)})')
+        _require(embed_b is None or (embed_w is not None and tuple(embed_b.shape) == (embed,)), 'mapping: embed bias must be [embed]')
+        _require(w_avg is None or w_avg.numel() == fc_ws[-1].shape[0], 'mapping: w_avg must have w_dim elements')
+        _require(num_ws >= 1, 'mapping: num_ws must be positive')
         k = z_dim + embed
         for w, b in zip(fc_ws, fc_bs):
             _require(w.ndim == 2 and w.shape[1] == k and (b is None or tuple(b.shape) == (w.shape[0],)), 'mapping: layer widths do not chain')
             k = w.shape[0]
         lib = load()
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev.index, _ws_domain(dev))
         wsp = MappingPlugin._ws.get(key)
         if wsp is None:
             wsp = MappingPlugin._ws[key] = torch.zeros([lib.ide3d_mapping_workspace_bytes() // 4 + 4], dtype=torch.float32, device=dev)

@@ -455,18 +455,27 @@ class GraphedRenderer:
         self.graph = None
         stream = torch.cuda.Stream(device=device)
         stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(stream), torch.no_grad():
+        # Every launch of the warm-up and of the capture takes its scratch memory (packed weights, split-K partials, the mapping
+        # kernel's barrier counter) from workspaces owned by THIS object (hip_plugin.workspace_scope), not by a stream handle that
+        # another graph or an eager caller may be handed as well; the replays reuse the copies packed during warm-up.
+        scope = self._scope(device)
+        with torch.cuda.stream(stream), torch.no_grad(), scope:
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(device).wait_stream(stream)
         torch.cuda.synchronize(device)
-        # capture on the warm-up stream: per-layer workspaces (packed weights) are keyed by stream, so the replays reuse the
-        # copies packed during warm-up instead of re-packing inside the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph, stream=stream):
+        with torch.no_grad(), scope, torch.cuda.graph(graph, stream=stream):
             self.out = self._body()
         self.graph = graph
         self._stream = stream
+
+    def _scope(self, device):
+        import contextlib
+        if torch.device(device).type != 'cuda':
+            return contextlib.nullcontext()
+        from torch_utils import hip_plugin
+        return hip_plugin.workspace_scope(self)
 
     def _body(self):
         ws = self.G.mapping(self.z, self.c_cond, truncation_psi=self.psi)

@@ -404,7 +404,7 @@ int ide3d_fold_heads(const float* w, int64_t w_stride, int32_t n, int32_t cin, i
  * dense float32 with the RAW parameters; the runtime gains are applied here like FullyConnectedLayer does
  * (weight_gain = lr_multiplier / sqrt(in), bias_gain = lr_multiplier; the embed layer's gains are passed explicitly).
  * ws [n, num_ws, fc_out[layers-1]] is written.  truncation_psi == 1 disables truncation; truncation_cutoff < 0 = all layers.
- * workspace: ide3d_mapping_workspace_bytes() bytes of device memory (activation ping-pong + barrier counter).
+ * workspace: ide3d_mapping_workspace_bytes() bytes of device memory (one activation buffer per layer + barrier counter + error word).
  * n <= 8, widths <= 1024 and multiples of 4; returns IDE3D_EINVAL otherwise (callers then use their generic path).
  */
 typedef struct ide3d_mapping_params {
@@ -421,6 +421,9 @@ typedef struct ide3d_mapping_params {
 } ide3d_mapping_params;
 
 int ide3d_mapping_workspace_bytes(void);
+/* 1 when the kernel's 64 workgroups are co-resident on the current device (its grid-wide barrier needs that; checked once against the
+ * occupancy query with a 2x margin), else 0: `ide3d_mapping` then returns IDE3D_ENOKERNEL and callers use their layer-by-layer path. */
+int ide3d_mapping_supported(void);
 int ide3d_mapping(const ide3d_mapping_params* p, void* stream);
 
 /* ---- resampling between the big kernels of G.synthesis ---------------------------------- */

@@ -17,10 +17,15 @@ sys.path.insert(0, os.path.join(ROOT, 'ide-3d_amd'))
 import torch  # noqa: E402
 
 
-def make(path, seed=0, tiny=False):
+def make(path, seed=0, tiny=False, tiny52=False):
     from training import triplane
     torch.manual_seed(seed)
-    G = triplane.TriPlaneGenerator(triplane.tiny_spec() if tiny else None).eval().requires_grad_(False)
+    spec = None
+    if tiny52:       # the tiny topology with the released model's decoder row: 32 colour features + 19 classes + sigma = 52 (extract_shapes.py:146)
+        spec = triplane.tiny_spec(plane_channels=32, feature_channels=32, seg_channels=19)
+    elif tiny:
+        spec = triplane.tiny_spec()
+    G = triplane.TriPlaneGenerator(spec).eval().requires_grad_(False)
     with open(path, 'wb') as f:
         pickle.dump(dict(G_ema=G, G=None, D=None, training_set_kwargs=None, augment_pipe=None), f)
     return G
@@ -31,6 +36,7 @@ if __name__ == '__main__':
     ap.add_argument('--out', default='random-init-ide3d-ffhq-64-512.pkl')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--tiny', action='store_true', help='the seconds-on-CPU test topology instead of the 64->512 generator')
+    ap.add_argument('--tiny52', action='store_true', help='the tiny topology with a 52-wide decoder row (32 features + 19 classes + sigma)')
     a = ap.parse_args()
-    G = make(a.out, a.seed, a.tiny)
+    G = make(a.out, a.seed, a.tiny, a.tiny52)
     print(f'wrote {a.out}: {sum(p.numel() for p in G.parameters()) / 1e6:.1f} M parameters, num_ws={G.num_ws}')

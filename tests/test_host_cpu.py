@@ -419,3 +419,34 @@ def test_full_spec_shapes():
     c = triplane.conditioning_label()
     assert c.shape == (1, 25) and float(c[0, 11]) == pytest.approx(2.7)
     assert_close(triplane.camera_label(0.0)[:, :16], c[:, :16], rtol=0, atol=1e-6, what='frontal pose == conditioning pose')
+
+
+def test_dnnlib_util_lazy_reference_import_failure_is_attribute_error(tmp_path):
+    """a reference dnnlib/util.py that fails to import (it imports `requests` ... at module level) must surface as
+    AttributeError from the overlay's module `__getattr__` — every time, not only on the first access — with the cause chained."""
+    code = r'''
+import os, sys
+overlay, fake = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.join(fake, 'dnnlib'))
+open(os.path.join(fake, 'dnnlib', '__init__.py'), 'w').write('')
+open(os.path.join(fake, 'dnnlib', 'util.py'), 'w').write('import a_module_that_does_not_exist_anywhere\n')
+sys.path[:0] = [overlay, fake]
+import dnnlib, dnnlib.util as u
+assert any(os.path.abspath(d) == os.path.join(fake, 'dnnlib') for d in dnnlib.__path__)
+for attempt in range(3):                      # the failure is cached: same answer on every access
+    assert not hasattr(u, 'format_time')
+    assert getattr(u, 'Logger', 'dflt') == 'dflt'
+    try:
+        u.make_cache_dir_path
+    except AttributeError as e:
+        assert isinstance(e.__cause__, ImportError) and isinstance(e.__cause__.__cause__, ModuleNotFoundError), repr(e.__cause__)
+    else:
+        raise SystemExit('expected AttributeError')
+assert callable(u.sample_from_triplane) and u.EasyDict(a=1).a == 1          # what the overlay states itself keeps working
+print('LAZY_OK')
+'''
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, '-c', code, os.path.join(ROOT, 'ide-3d_amd'), str(tmp_path / 'fake_ref')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and 'LAZY_OK' in res.stdout, res.stdout[-3000:]
