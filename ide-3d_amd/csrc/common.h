@@ -62,6 +62,37 @@ __host__ __device__ __forceinline__ int floordiv(int a, int b) {
     return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
+// Raise slot (blockIdx.x % IDE3D_AMAX_SLOTS) of image n's amax row to v (v >= 0, finite): called ONCE per workgroup (callers reduce
+// inside the workgroup first).  The slot is read first (an L2 read that bypasses this CU's L1): a running maximum converges after a
+// few workgroups, so almost every call ends without the atomic.  (First version, measured: one atomic per wave on one word per image
+// = 38 ms per frame instead of 5; per-wave reads of 32 words in ONE cache line still cost 3 ms per frame.)
+__device__ __forceinline__ void amax_raise(float* amax, int n, float v) {
+    unsigned* const slot = reinterpret_cast<unsigned*>(amax) + (size_t)n * IDE3D_AMAX_FLOATS + (blockIdx.x % IDE3D_AMAX_SLOTS) * IDE3D_AMAX_STRIDE;
+    const unsigned bits = __float_as_uint(v);
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+// Workgroup maximum of v (>= 0) through `scratch` (>= blockDim.x / 64 floats of LDS nobody else uses between the two barriers inside),
+// then one amax_raise by thread 0.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void amax_raise_block(float* amax, int n, float v, float* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = scratch[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, scratch[i]);
+        if (m > 0.f) amax_raise(amax, n, m);
+    }
+}
+// amax of a grid-stride element-wise kernel whose threads may see several images: per-workgroup maxima per image in LDS (atomic
+// maxima on `s_am[64]`, images folded modulo 64: p_n <= 64 required), then one amax_raise per image and workgroup.
+__device__ __forceinline__ void amax_lds_flush(unsigned* s_am, int n, float v) { if (v > 0.f) atomicMax(&s_am[n & 63], __float_as_uint(v)); }
+__device__ __forceinline__ void amax_lds_commit(float* amax, const unsigned* s_am, int p_n) {
+    __syncthreads();
+    if ((int)threadIdx.x < p_n && threadIdx.x < 64 && s_am[threadIdx.x] != 0u) amax_raise(amax, (int)threadIdx.x, __uint_as_float(s_am[threadIdx.x]));
+}
+
 __host__ __device__ __forceinline__ int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ __forceinline__ int     cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -173,10 +173,23 @@ __host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3
 // acc[class][m tile][n tile] in the 32x32 MFMA C layout; `lp` = the pixel (0..31, in tile order) that this lane's MFMA column
 // holds inside each 32-pixel N tile (the lane's own index for the fp32 path; a permutation for the split-bf16 path).
 // `s_w`: LDS scratch of SCRATCH floats that the main loop has finished with (the caller's last barrier covers it).
+// `row_unscale` / `x_unscale`: the f16x3 loop computes with weights scaled per output row and the patch scaled per image (exact powers
+// of two); both are undone here together with the demodulation (also for split-K partials, which are stored unscaled).
+// `p.y_amax` (optional): max |finished value| per image, for the consumer's f16x3 scale (wave reduction + one atomic per wave and tile).
+// running maximum of |v| over FINITE values: an inf / NaN element must not decide the scale of its whole image (its own piece
+// becomes inf / NaN in any arithmetic; the finite rest keeps its precision)
+__device__ __forceinline__ void amax_acc(float& m, float v) {
+    const float a = fabsf(v);
+    m = fmaxf(m, a < __builtin_inff() ? a : 0.f);
+}
+__device__ __forceinline__ void amax_commit(float* y_amax, int n, float v, bool) {       // several images per tile (tiny layers): per lane
+    if (v > 0.f) amax_raise(y_amax, n, v);
+}
+
 template <int MODE, int TI, int PH, int PW, int NWV, int NCLS, int MTW, int NTW, int BM, int SCRATCH>
 __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, float* __restrict__ partial, const ConvGeom& g,
                                                f32x16 (&acc)[NCLS][MTW][NTW], float* s_w, int mb, int n0, int y0, int x0, int split, int cls,
-                                               int wm, int wn, int lp) {
+                                               int wm, int wn, int lp, const float* __restrict__ row_unscale = nullptr, float x_unscale = 1.f) {
     constexpr int NT = 64 * NWV;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
     const int cpy = cls >> 1, cpx = cls & 1;
@@ -188,7 +201,9 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
     float* const s_bi = s_w + TI * BM;          // [BM]
     for (int e = tid; e < TI * BM; e += NT) {
         const int rl = e % BM, co = mb * BM + rl, n = min(n0 + e / BM, p.n - 1);
-        s_dm[e] = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
+        float d = (!raw && p.dcoefs && co < p.cout) ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
+        if (row_unscale) d *= row_unscale[co] * x_unscale;        // exact: powers of two
+        s_dm[e] = d;
         if (e < BM) s_bi[e] = (!raw && p.bias && co < p.cout) ? p.bias[co] : 0.f;
     }
     __syncthreads();
@@ -204,6 +219,8 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
         v *= e_gain;
         return fminf(fmaxf(v, -e_clamp), e_clamp);
     };
+    const bool want_amax = !raw && p.y_amax != nullptr;
+    float amax_tile = 0.f;                                   // TI == 1: one image per tile, reduced once at the end
     // Vector epilogue: a lane holds ONE pixel of 16 channels per accumulator, i.e. 4-byte stores and 16 different
     // demodulation / bias values.  RR channel rows of raw accumulators go through a wave-private LDS tile ([row][pixel], the
     // two x-parity classes of the all-class transposed convolution interleaved); a lane then takes 4 consecutive output
@@ -233,6 +250,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
                 else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[pofs + e] * e_nstr;
             }
             float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * g.ow) + pofs;
+            float amax_j = 0.f;
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -254,10 +272,13 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
                     float* o = o_px + (int64_t)co * ((int64_t)g.oh * g.ow);
-                    if (full) *reinterpret_cast<f32x4u*>(o) = v4;
-                    else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) o[e] = v4[e];
+                    if (full) {
+                        *reinterpret_cast<f32x4u*>(o) = v4;
+                        if (want_amax) { amax_acc(amax_j, v4[0]); amax_acc(amax_j, v4[1]); amax_acc(amax_j, v4[2]); amax_acc(amax_j, v4[3]); }
+                    } else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) { o[e] = v4[e]; amax_acc(amax_j, v4[e]); }
                 }
             }
+            if (want_amax) { if (TI == 1) amax_tile = fmaxf(amax_tile, amax_j); else if (px_ok) amax_commit(p.y_amax, n, amax_j, false); }
         }
     } else {
 #pragma unroll
@@ -272,6 +293,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
         const bool ok = n < p.n && oy < g.oh && ox < g.ow;
         if (!ok) continue;
         const float nz = (e_nstr != 0.f) ? p.noise[oy * g.ow + ox] * e_nstr : 0.f;
+        float amax_j = 0.f;
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -279,10 +301,15 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
                 const int rl = (wm * MTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the block
                 const int co = mb * BM + rl;
                 if (co >= p.cout) continue;
-                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = finish(acc[q][i][j][r], s_dm[ti * BM + rl], nz, s_bi[rl]);
+                const float v = finish(acc[q][i][j][r], s_dm[ti * BM + rl], nz, s_bi[rl]);
+                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = v;
+                amax_acc(amax_j, v);
             }
+        if (want_amax) { if (TI == 1) amax_tile = fmaxf(amax_tile, amax_j); else amax_commit(p.y_amax, n, amax_j, false); }
     }
     }
+    if (TI == 1 && p.y_amax != nullptr && !raw && n0 < p.n)        // (uniform over the workgroup) one read / atomic per tile
+        amax_raise_block(p.y_amax, n0, amax_tile, s_w);          // its first barrier: every thread has finished reading s_dm / s_bi / T
 }
 
 // One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
@@ -586,21 +613,62 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-// a, b -> PARTS packed bf16 pairs whose sums reproduce a and b (residuals are exact in fp32)
-template <int PARTS>
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// a, b -> PARTS packed bf16 (F16: fp16, round to nearest even, v_cvt_pk_f16_f32) pairs whose sums reproduce a and b (residuals are
+// exact in fp32)
+template <int PARTS, int F16 = 0>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PARTS]) {
+    if constexpr (F16) {
+        static_assert(PARTS == 2, "the fp16 split has two pieces");
+        const f32x2 v = {a, b};
+        const f16x2 hi = __builtin_convertvector(v, f16x2);
+        const f32x2 r = {a - (float)hi.x, b - (float)hi.y};
+        const f16x2 lo = __builtin_convertvector(r, f16x2);
+        out[0] = __builtin_bit_cast(unsigned, hi); out[1] = __builtin_bit_cast(unsigned, lo);
+    } else {
 #pragma unroll
     for (int q = 0; q < PARTS; ++q) {
         const unsigned pk = pk_bf16(a, b);
         out[q] = pk;
         if (q + 1 < PARTS) { a -= __uint_as_float(pk << 16); b -= __uint_as_float(pk & 0xffff0000u); }
     }
+    }
+}
+template <int F16>
+__device__ __forceinline__ f32x16 sp_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// exact power-of-two scale that brings `bound` (> 0, finite) just below 2^15 (fp16 overflows at 65504): (scale, 1 / scale); (1, 1) for
+// zero / non-finite bounds.  The exponent is kept inside +-126 so that neither factor leaves the normal fp32 range.
+__device__ __forceinline__ void f16_scale(float bound, float& scale, float& unscale) {
+    scale = 1.f; unscale = 1.f;
+    if (bound > 0.f && bound < __builtin_inff()) {
+        int e;
+        frexpf(bound, &e);                                  // bound = m * 2^e, m in [0.5, 1)
+        e = min(max(15 - e, -126), 126);
+        scale = ldexpf(1.f, e); unscale = ldexpf(1.f, -e);
+    }
+}
+
+// f16x3: per-row scales of the weights w [cout, rowlen]: scale[row] * max |w[row]| in [2^14, 2^15); rows >= cout: 1
+__global__ void __launch_bounds__(256)
+modconv_row_scale_kernel(const float* __restrict__ w, int cout, int rowlen, int rows_padded, float* __restrict__ scale, float* __restrict__ unscale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows_padded) return;
+    float m = 0.f;
+    if (row < cout) for (int i = lane; i < rowlen; i += 64) m = fmaxf(m, fabsf(w[(int64_t)row * rowlen + i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) { float sc, us; f16_scale(m, sc, us); scale[row] = sc; unscale[row] = us; }
 }
 
 // weights w [cout, cin, 3, 3] -> [mb][chunk][ky][kx][part][k half][co][8 channels] bf16 (zero padded)
-template <int PARTS>
+template <int PARTS, int F16 = 0>
 __global__ void __launch_bounds__(256)
-modconv_pack_split_kernel(const float* __restrict__ w, int cout, int cin, int bm, int mblocks, int cchunks, u32x4* __restrict__ out) {
+modconv_pack_split_kernel(const float* __restrict__ w, int cout, int cin, int bm, int mblocks, int cchunks, u32x4* __restrict__ out,
+                          const float* __restrict__ row_scale = nullptr) {
     const int64_t total = (int64_t)mblocks * cchunks * 9 * 2 * bm;   // one thread per (mb, chunk, tap, k half, co): all parts
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -611,13 +679,14 @@ modconv_pack_split_kernel(const float* __restrict__ w, int cout, int cin, int bm
         const int cc = (int)(r % cchunks); r /= cchunks;
         const int mb = (int)r;
         const int co = mb * bm + co_l;
+        const float rs = F16 ? row_scale[co] : 1.f;
         unsigned pk[4][PARTS];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ci = cc * 16 + kg * 8 + e * 2;
-            const float a = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 9 + tap] : 0.f;
-            const float b = (co < cout && ci + 1 < cin) ? w[((int64_t)co * cin + ci + 1) * 9 + tap] : 0.f;
-            split_pair<PARTS>(a, b, pk[e]);
+            const float a = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 9 + tap] * rs : 0.f;
+            const float b = (co < cout && ci + 1 < cin) ? w[((int64_t)co * cin + ci + 1) * 9 + tap] * rs : 0.f;
+            split_pair<PARTS, F16>(a, b, pk[e]);
         }
         const int64_t base = (((int64_t)(mb * cchunks + cc) * 9 + tap) * PARTS * 2 + kg) * bm + co_l;
 #pragma unroll
@@ -638,10 +707,12 @@ template <int PENDING>
 __device__ __forceinline__ void lds_wait128(u32x4& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
 __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV>
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
-                                                   const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x) {
+                                                   const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x,
+                                                   const float* __restrict__ row_unscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
+    static_assert(!F16 || PARTS == 2, "f16x3 = two fp16 pieces per operand");
     constexpr int PW = K::PW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -677,6 +748,24 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const float* __restrict__ ximg = p.x + (int64_t)n0 * p.cin * hw;
     float xreg[K::NXR][4];
     float sty[4];
+    // f16x3: scale of this image's patch, from the bound max |x| (p.x_amax) * max |style| (exact power of two, folded into the styles)
+    float xs = 1.f, xus = 1.f;
+    if constexpr (F16) {
+        float m = p.styles ? 0.f : 1.f;
+        if (p.styles) for (int ci = tid; ci < p.cin; ci += K::NT) m = fmaxf(m, fabsf(p.styles[(int64_t)n0 * p.cin + ci]));
+        float xm = (tid < IDE3D_AMAX_SLOTS) ? p.x_amax[(int64_t)n0 * IDE3D_AMAX_FLOATS + tid * IDE3D_AMAX_STRIDE] : 0.f;      // wave 0 holds the whole row
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off)); xm = fmaxf(xm, __shfl_xor(xm, off)); }
+        float* const red = reinterpret_cast<float*>(smem);
+        if (lane == 0) { red[wid] = m; if (wid == 0) red[NWV] = xm; }
+        __syncthreads();
+        float mm = red[0];
+#pragma unroll
+        for (int i = 1; i < NWV; ++i) mm = fmaxf(mm, red[i]);
+        xm = red[NWV];
+        __syncthreads();                                      // before the weight DMA / patch commit overwrite the scratch
+        f16_scale(mm * xm, xs, xus);
+    }
     const bool stages_patch = (NWV == 4) || wid < 4;
     auto fetch_patch = [&](int c) {
         if (!stages_patch) return;
@@ -684,7 +773,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ci = min(ci0 + k, p.cin - 1);
-            sty[k] = (ci0 + k < p.cin) ? (p.styles ? p.styles[(int64_t)n0 * p.cin + ci] : 1.f) : 0.f;
+            sty[k] = (ci0 + k < p.cin) ? (p.styles ? p.styles[(int64_t)n0 * p.cin + ci] : 1.f) * xs : 0.f;
 #pragma unroll
             for (int r = 0; r < K::NXR; ++r) xreg[r][k] = ximg[(int64_t)ci * hw + max(x_src[r], 0)];
         }
@@ -697,8 +786,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             const int sidx = lane + 64 * r;
             const bool live = x_src[r] >= 0;
             unsigned lo[PARTS], hi[PARTS];
-            split_pair<PARTS>(live ? xreg[r][0] * sty[0] : 0.f, live ? xreg[r][1] * sty[1] : 0.f, lo);
-            split_pair<PARTS>(live ? xreg[r][2] * sty[2] : 0.f, live ? xreg[r][3] * sty[3] : 0.f, hi);
+            split_pair<PARTS, F16>(live ? xreg[r][0] * sty[0] : 0.f, live ? xreg[r][1] * sty[1] : 0.f, lo);
+            split_pair<PARTS, F16>(live ? xreg[r][2] * sty[2] : 0.f, live ? xreg[r][3] * sty[3] : 0.f, hi);
             if (sidx < K::NSLOT) {
 #pragma unroll
                 for (int q = 0; q < PARTS; ++q) {
@@ -815,8 +904,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
                             for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
                                 for (int j = 0; j < K::NTW; ++j)
-                                    acc[QC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[B][i][qa]),
-                                                                                            __builtin_bit_cast(bf16x8, bv[B][j][qb]), acc[QC][i][j], 0, 0, 0);
+                                    acc[QC][i][j] = sp_mfma<F16>(av[B][i][qa], bv[B][j][qb], acc[QC][i][j]);
                         }
                     }
             });
@@ -834,7 +922,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 #ifdef IDE3D_MC_TRACE
     const unsigned long long mc_t1 = __builtin_readcyclecounter();
 #endif
-    modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp);
+    modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp,
+                                                                                                F16 ? row_unscale : nullptr, xus);
 #ifdef IDE3D_MC_TRACE
     if (blockIdx.x == 100 && (threadIdx.x == 0 || threadIdx.x == 256)) {          // wave 0 (and wave 4 of an 8-wave workgroup, at [16..])
         const int o = threadIdx.x ? 16 : 0;
@@ -1027,16 +1116,16 @@ constexpr int sp_waves_per_simd() {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     return (NWV == 8) ? 2 : (!kSpExclusive && K::LDS_BYTES <= 80 * 1024 && (WBUF == 1 || K::NCLS * K::MTW * K::NTW <= 8)) ? 2 : 1;
 }
-template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4>
+template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4, int F16 = 0>
 __global__ void __launch_bounds__(64 * NWV, (sp_waves_per_simd<MODE, BIG, PH, PARTS, WBUF, NWV>()))
-modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g) {
+modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
 #ifdef IDE3D_SP_EXCLUSIVE_SIMD
     if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255");
 #endif
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
-    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0]);
+    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
 }
 
 // reduce split-K partials + epilogue
@@ -1044,6 +1133,10 @@ __global__ void __launch_bounds__(256)
 modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partial, int split_k, int oh, int ow) {
     const int64_t per = (int64_t)p.n * p.cout * oh * ow;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int am_n = -1; float am = 0.f;
+    __shared__ unsigned s_am[64];
+    const bool am_lds = p.y_amax && p.n <= 64;                  // per-workgroup maxima in LDS, one global update per image and workgroup
+    if (p.y_amax) { if (threadIdx.x < 64) s_am[threadIdx.x] = 0u; __syncthreads(); }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += stride) {
         float v = 0.f;
         for (int s = 0; s < split_k; ++s) v += partial[s * per + i];
@@ -1057,6 +1150,14 @@ modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partia
         v *= p.gain;
         if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
         p.y[i] = v;
+        if (p.y_amax) {                                          // small layers only (split-K): per-thread running maximum per image
+            if (n != am_n) { if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else amax_commit(p.y_amax, am_n, am, false); } am_n = n; am = 0.f; }
+            amax_acc(am, v);
+        }
+    }
+    if (p.y_amax) {
+        if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else amax_commit(p.y_amax, am_n, am, false); }
+        if (am_lds) amax_lds_commit(p.y_amax, s_am, p.n);
     }
 }
 
@@ -1067,8 +1168,9 @@ modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partia
 struct ConvPlan {
     int mode, big, tile;             // tile: 0 = 1x8x16, 1 = 2x8x8, 2 = 8x4x4
     int bm, kc, taps, mblocks, cchunks, oh, ow;
-    int parts;                       // 0: fp32 MFMA loop; 2 / 3: split-bf16 loop with that many pieces per operand
-    int64_t packed_floats, partial_floats;
+    int parts;                       // 0: fp32 MFMA loop; 2 / 3: split loop with that many pieces per operand
+    int f16;                         // split loop on fp16 pieces (f16x3: parts == 2) instead of bf16
+    int64_t packed_floats, aux_floats, partial_floats;      // aux: per-row scale + unscale of the f16x3 weights
     ConvGeom g;
 };
 
@@ -1094,21 +1196,23 @@ static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
 }
 
 // Arithmetic of the big 3x3 layers: 1 = fp32 MFMA (exact fp32 products), 6 = three bf16 pieces per operand / 6 products
-// (fp32-grade), 3 = two pieces / 3 products (~2^-17 relative per product).  Process default: IDE3D_CONV_ARITH, else bf16x6 (its
-// error against a float64 convolution equals the fp32 MFMA's within the noise: tests/test_gpu_conv_arith.py).
+// (fp32-grade), 3 = two pieces / 3 products (~2^-17 relative per product), 16 = two fp16 pieces / 3 products with exact power-of-two
+// range scales (~2^-21; needs x_amax).  Process default: IDE3D_CONV_ARITH, else fp32 — the split arithmetics are opt-in (a foreign
+// kernel's packed-fp32 wave beside an LDS-fed bf16 / fp16 MFMA loop returns wrong results on MI355X: DESIGN.md section 4.2).
 static int g_conv_arith = 0;
 static int conv_arith_default() {
     if (g_conv_arith) return g_conv_arith;
     static const int env = [] {
         const char* e = getenv("IDE3D_CONV_ARITH");
-        if (!e) return 6;
+        if (!e) return 1;
         if (!strcmp(e, "bf16x3") || !strcmp(e, "3")) return 3;
-        if (!strcmp(e, "fp32") || !strcmp(e, "1")) return 1;
-        return 6;
+        if (!strcmp(e, "bf16x6") || !strcmp(e, "6")) return 6;
+        if (!strcmp(e, "f16x3") || !strcmp(e, "16")) return 16;
+        return 1;
     }();
     return env;
 }
-static int resolve_arith(int a) { return (a == 1 || a == 3 || a == 6) ? a : conv_arith_default(); }
+static int resolve_arith(int a) { return (a == 1 || a == 3 || a == 6 || a == 16) ? a : conv_arith_default(); }
 
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
@@ -1135,7 +1239,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
     pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
-    pl.parts = 0;
+    pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0;
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -1177,7 +1281,8 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 && p.cin > 32 &&
         (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8 &&
         (!getenv("IDE3D_MODCONV_SP_MODES") || (atoi(getenv("IDE3D_MODCONV_SP_MODES")) & (pl.mode == MODE_CONV3 ? 1 : 2)))) {
-        pl.parts = (arith == 3) ? 2 : 3;
+        pl.parts = (arith == 3 || arith == 16) ? 2 : 3;
+        pl.f16 = (arith == 16) ? 1 : 0;
         static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
         if (pl.mode == MODE_CONV3) {
             if (sp_rows == 8) pl.tile = 0;
@@ -1193,9 +1298,11 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         const int lds = 2 * 16 * (3 * pl.parts * 2 * pl.bm + pl.parts * 2 * (ph + 2) * 18);
         if (sp_maxlds && lds > sp_maxlds) pl.parts = 0;
     }
+    if (!pl.parts) pl.f16 = 0;
     if (pl.parts) {
         pl.kc = 16; pl.cchunks = cdiv(p.cin, 16);
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
+        if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
     }
     static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
     ConvGeom& g = pl.g;
@@ -1246,24 +1353,25 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
 }
 
 
-template <int MODE, int BIG, int PARTS>
+template <int MODE, int BIG, int PARTS, int F16 = 0>
 static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
-    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g); }
+    const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [scale | unscale] behind the packed weights
+    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru); }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr;
-        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
         // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6;
         // the all-class transposed form keeps 4 waves: 279 vs 268 us); IDE3D_MODCONV_SP_W4 = 4 waves everywhere
         static const bool eight = getenv("IDE3D_MODCONV_SP_W4") == nullptr && MODE == MODE_CONV3;
-        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g);
+        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
 }
 
@@ -1298,11 +1406,11 @@ extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t
     p.x = nullptr;                               // alignment of the real tensor is unknown here: size for the larger plan
     // sized for every arithmetic (the packed copy of the split-bf16 loops is the larger one) and for the flattened 1x1 plan
     int64_t packed = 0, part = 0;
-    for (int arith : {1, 3, 6}) {
+    for (int arith : {1, 3, 6, 16}) {
         ConvPlan pl; plan_conv(p, pl, arith);
         ConvPlan pf; plan_conv(flatten_pointwise(p), pf, arith);
         for (const ConvPlan* q : {&pl, &pf}) {
-            if (q->packed_floats > packed) packed = q->packed_floats;
+            if (q->packed_floats + q->aux_floats > packed) packed = q->packed_floats + q->aux_floats;
             if (q->partial_floats > part) part = q->partial_floats;
         }
     }
@@ -1324,7 +1432,7 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
     hipStream_t st_head = (hipStream_t)stream;
     if (head_split_applies(p, resolve_arith(p.arith))) {
-        const int parts = resolve_arith(p.arith) == 3 ? 2 : 3, mt = p.cout <= 32 ? 1 : 6, cchunks = cdiv(p.cin, 16);
+        const int parts = resolve_arith(p.arith) == 3 ? 2 : 3, mt = p.cout <= 32 ? 1 : 6, cchunks = cdiv(p.cin, 16);     // f16x3: the heads stay on bf16x6
         IDE3D_CHECK_ARG(p.workspace_bytes >= head_packed_units(p.n, cchunks, parts, mt) * 16, "modconv2d: workspace too small for the packed head weights");
         u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
         const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
@@ -1338,21 +1446,30 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         IDE3D_CHECK_LAUNCH("modconv2d (split-bf16 heads)");
         return IDE3D_OK;
     }
-    ConvPlan pl; plan_conv(p, pl, resolve_arith(p.arith));
-    IDE3D_CHECK_ARG(p.workspace_bytes >= (pl.packed_floats + pl.partial_floats) * (int64_t)sizeof(float),
-                    "modconv2d: workspace too small (need %lld bytes)", (long long)((pl.packed_floats + pl.partial_floats) * sizeof(float)));
+    // f16x3 needs the caller's bound on |x| (x_amax); without it the launch runs in bf16x6 (same interface, no range to manage)
+    int arith_eff = resolve_arith(p.arith);
+    if (arith_eff == 16 && !p.x_amax) arith_eff = 6;
+    ConvPlan pl; plan_conv(p, pl, arith_eff);
+    IDE3D_CHECK_ARG(p.workspace_bytes >= (pl.packed_floats + pl.aux_floats + pl.partial_floats) * (int64_t)sizeof(float),
+                    "modconv2d: workspace too small (need %lld bytes)", (long long)((pl.packed_floats + pl.aux_floats + pl.partial_floats) * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
     float* wp = p.workspace;
-    float* partial = p.workspace + pl.packed_floats;
+    float* partial = p.workspace + pl.packed_floats + pl.aux_floats;
     if (pl.parts) {
         if (!p.weights_packed) {
             const int64_t items = (int64_t)pl.mblocks * pl.cchunks * 9 * 2 * pl.bm;
-            if (pl.parts == 2) hipLaunchKernelGGL(modconv_pack_split_kernel<2>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp));
-            else               hipLaunchKernelGGL(modconv_pack_split_kernel<3>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp));
+            if (pl.f16) {
+                float* const rs = wp + pl.packed_floats;                  // [rows] scale, then [rows] unscale
+                const int rows = pl.mblocks * pl.bm;
+                hipLaunchKernelGGL(modconv_row_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p.w, p.cout, p.cin * 9, rows, rs, rs + rows);
+                hipLaunchKernelGGL((modconv_pack_split_kernel<2, 1>), dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), rs);
+            }
+            else if (pl.parts == 2) hipLaunchKernelGGL(modconv_pack_split_kernel<2>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
+            else               hipLaunchKernelGGL(modconv_pack_split_kernel<3>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
         }
 #define IDE3D_SP_DISPATCH(M) \
-        do { if (pl.big == 1) { if (pl.parts == 2) launch_split<M, 1, 2>(p, pl, wp, partial, st); else launch_split<M, 1, 3>(p, pl, wp, partial, st); } \
-             else             { if (pl.parts == 2) launch_split<M, 2, 2>(p, pl, wp, partial, st); else launch_split<M, 2, 3>(p, pl, wp, partial, st); } } while (0)
+        do { if (pl.big == 1) { if (pl.f16) launch_split<M, 1, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 1, 2>(p, pl, wp, partial, st); else launch_split<M, 1, 3>(p, pl, wp, partial, st); } \
+             else             { if (pl.f16) launch_split<M, 2, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 2, 2>(p, pl, wp, partial, st); else launch_split<M, 2, 3>(p, pl, wp, partial, st); } } while (0)
         if (pl.mode == MODE_CONV3) IDE3D_SP_DISPATCH(MODE_CONV3); else IDE3D_SP_DISPATCH(MODE_TCONV3A);
 #undef IDE3D_SP_DISPATCH
     } else {
@@ -1379,7 +1496,8 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
 }
 
 extern "C" int ide3d_set_conv_arithmetic(int32_t arith) {
-    IDE3D_CHECK_ARG(arith == 0 || arith == 1 || arith == 3 || arith == 6, "set_conv_arithmetic: 0 (environment default), 1 (fp32), 3 (bf16x3) or 6 (bf16x6)");
+    IDE3D_CHECK_ARG(arith == 0 || arith == 1 || arith == 3 || arith == 6 || arith == 16,
+                    "set_conv_arithmetic: 0 (environment default), 1 (fp32), 3 (bf16x3), 6 (bf16x6) or 16 (f16x3)");
     ide3d::g_conv_arith = arith;
     return IDE3D_OK;
 }

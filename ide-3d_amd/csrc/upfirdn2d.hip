@@ -96,6 +96,10 @@ upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, 
     T* __restrict__ y = (T*)p.y;
     const int64_t total = (int64_t)p.n * p.c * p.out_h * p.out_w;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int am_n = -1; float am = 0.f;
+    __shared__ unsigned s_am[64];
+    const bool am_lds = ep.y_amax && p.n <= 64;
+    if (ep.y_amax) { if (threadIdx.x < 64) s_am[threadIdx.x] = 0u; __syncthreads(); }
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         int ox, oy, c, n;
         int64_t r = idx;
@@ -136,8 +140,16 @@ upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, 
                 acc += Elem<T>::ld(xr + (int64_t)(ix0 + tx) * p.x_stride[3]) * (M)fr[fx * p.f_stride[1]];
             }
         }
-        Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3],
-                    apply_epilogue<T>(acc * (M)p.gain, ep, n, c, oy, ox, p.out_w));
+        const M out = apply_epilogue<T>(acc * (M)p.gain, ep, n, c, oy, ox, p.out_w);
+        Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3], out);
+        if (ep.y_amax) {                                          // running maximum per image, flushed when the image changes
+            if (n != am_n) { if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else if (am > 0.f) amax_raise(ep.y_amax, am_n, am); } am_n = n; am = 0.f; }
+            { const float a = fabsf((float)out); am = fmaxf(am, a < __builtin_inff() ? a : 0.f); }
+        }
+    }
+    if (ep.y_amax) {
+        if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else if (am > 0.f) amax_raise(ep.y_amax, am_n, am); }
+        if (am_lds) amax_lds_commit(ep.y_amax, s_am, p.n);
     }
 }
 
@@ -241,6 +253,7 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
         for (int wx = 0; wx < WX; ++wx)
             win[wy][wx] = s_in[(ly0 + wy) * LW + lx0 + wx];
 
+    float amax_t = 0.f;
     T* __restrict__ yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
     const T* add_plane = ep.add ? (const T*)ep.add + (int64_t)n * ep.add_stride[0] + (int64_t)c * ep.add_stride[1] : nullptr;
     const M bias = (ep.fused_act && ep.bias) ? (M)Elem<T>::ld((const T*)ep.bias + c) : (M)0;
@@ -274,6 +287,9 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
             constexpr int NO = CX * UX;
             const bool full = ox0 >= 0 && ox0 + NO <= p.out_w;
             epilogue_row<T, NO>(row, ep, add_plane, bias, oy, ox0, p.out_w, full);
+#pragma unroll
+            for (int j = 0; j < NO; ++j)
+                if (full || (ox0 + j >= 0 && ox0 + j < p.out_w)) { const float a = fabsf((float)row[j]); amax_t = fmaxf(amax_t, a < __builtin_inff() ? a : 0.f); }   // finite values only
             if constexpr (sizeof(T) == 4 && NO == 4) {
                 if (full && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
                     float4 v4 = make_float4(row[0], row[1], row[2], row[3]);
@@ -287,6 +303,8 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
                 if (ox >= 0 && ox < p.out_w) Elem<T>::st(yr + ox, row[j]);
             }
         }
+    // max |finished output| of this tile's image for the consumer's f16x3 scale (a tile belongs to one (image, channel) plane)
+    if (ep.y_amax) amax_raise_block(ep.y_amax, n, amax_t, reinterpret_cast<float*>(s_in));      // one read / atomic per tile
 }
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>

@@ -20,7 +20,9 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 1
+_ABI_VERSION = 2
+AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
+AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
@@ -61,6 +63,7 @@ class _UpfirdnEpilogue(ctypes.Structure):
         ('bias', ctypes.c_void_p),
         ('fused_act', ctypes.c_int32), ('act', ctypes.c_int32),
         ('alpha', ctypes.c_float), ('act_gain', ctypes.c_float), ('clamp', ctypes.c_float),
+        ('y_amax', ctypes.c_void_p),
     ]
 
 
@@ -116,6 +119,7 @@ class _ModconvParams(ctypes.Structure):
         ('mode', ctypes.c_int32), ('weights_packed', ctypes.c_int32),
         ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
         ('w_batch_stride', ctypes.c_int64), ('arith', ctypes.c_int32),
+        ('x_amax', ctypes.c_void_p), ('y_amax', ctypes.c_void_p),
     ]
 
 
@@ -346,7 +350,7 @@ class Upfirdn2dPlugin:
 
     @staticmethod
     def upfirdn2d_ex(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain,
-                     add=None, noise=None, noise_strength=1.0, bias=None, act=None, alpha=0.0, act_gain=1.0, clamp=-1.0):
+                     add=None, noise=None, noise_strength=1.0, bias=None, act=None, alpha=0.0, act_gain=1.0, clamp=-1.0, y_amax=None):
         """upfirdn2d with the optional fused epilogue  y = bias_act(FIR(x) + add + noise * noise_strength)
         (`act` None = no bias/activation stage; 1 linear, 3 lrelu)."""
         _require(x.is_cuda, 'x must reside on CUDA device')
@@ -378,13 +382,17 @@ class Upfirdn2dPlugin:
         p.up_x, p.up_y, p.down_x, p.down_y = upx, upy, downx, downy
         p.pad_x0, p.pad_y0 = padx0, pady0
         p.flip, p.gain = int(bool(flip)), float(gain)
-        plain = add is None and noise is None and act is None
+        plain = add is None and noise is None and act is None and y_amax is None
         with torch.cuda.device(x.device):
             if plain:
                 rc = load().ide3d_upfirdn2d(ctypes.byref(p), _stream(x))
             else:
                 ep = _UpfirdnEpilogue()
                 keep = []
+                if y_amax is not None:     # [n, AMAX_FLOATS] float32, zeroed by the caller: row max = max |y| per image (f16x3 scale of the consumer)
+                    _require(y_amax.is_cuda and y_amax.device == x.device and y_amax.dtype == torch.float32 and tuple(y_amax.shape) == (n, AMAX_FLOATS)
+                             and y_amax.is_contiguous() and x.dtype == torch.float32, 'y_amax must be a contiguous float32 [n, AMAX_FLOATS] tensor on the device of a float32 x')
+                    ep.y_amax = y_amax.data_ptr()
                 if add is not None:
                     _require(add.shape == y.shape and add.dtype == x.dtype and add.device == x.device, 'add must match the output')
                     ep.add, ep.add_stride = add.data_ptr(), _i64x4(add.stride())
@@ -738,8 +746,10 @@ class ModconvPlugin:
     _ws = {}
 
     @staticmethod
-    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0, arith=0):
-        """arith: 0 = process default (`conv_arithmetic`), 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (include/ide3d_hip.h).
+    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0, arith=0, x_amax=None, y_amax=None):
+        """arith: 0 = process default (`conv_arithmetic`), 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6, 16 = f16x3 (include/ide3d_hip.h).
+        x_amax [n, AMAX_FLOATS]: row max = bound of max |x| per image (the f16x3 arithmetic needs it; else it runs bf16x6);
+        y_amax [n, AMAX_FLOATS], zeroed: its row maxima receive max |finite y| per image.
         mode 0: stride-1 k x k (modulated) conv, "same" padding, fused epilogue; mode 1: 3x3 stride-2 conv without padding
         (output ((h-3)//2+1) x ((w-3)//2+1)); mode 2: 3x3 transposed stride-2 conv (output (2h+1) x (2w+1)).
         styles / dcoefs / noise / bias may be None."""
@@ -761,6 +771,8 @@ class ModconvPlugin:
         # time; the domain is the current stream for eager callers and the owning GraphedRenderer inside `workspace_scope`
         # ... and per arithmetic: the packed weights of the split-bf16 loops differ from the fp32 loop's
         arith = int(arith) or int(lib.ide3d_get_conv_arithmetic())
+        if arith == 16 and x_amax is None:
+            arith = 6          # f16x3 needs the bound on |x|; decided here so that the workspace (packed weights) is the bf16x6 one
         key = (0 if per_image else w.data_ptr(), tuple(w.shape), n, h, wd, mode, x.device.index, _ws_domain(x.device), arith)
         ent = ModconvPlugin._ws.get(key)
         if ent is None:
@@ -791,6 +803,11 @@ class ModconvPlugin:
         p.weights_packed = int((not per_image) and ent[2] is not None and ent[2]() is w and ent[1] == w._version)
         p.w_batch_stride = (cout * cin * k * k) if per_image else 0
         p.arith = arith
+        for name, t in (('x_amax', x_amax), ('y_amax', y_amax)):
+            if t is not None:
+                _require(t.is_cuda and t.device == x.device and t.dtype == torch.float32 and tuple(t.shape) == (n, AMAX_FLOATS) and t.is_contiguous(),
+                         f'modconv2d: {name} must be a contiguous float32 [n, AMAX_FLOATS] tensor on the device of x')
+                setattr(p, name, t.data_ptr())
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         with torch.cuda.device(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
@@ -799,19 +816,29 @@ class ModconvPlugin:
         return y
 
 
-_ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'default': 0}
+_ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'f16x3': 16, 'default': 0}
 
 
 def conv_arithmetic(name=None):
     """Get (no argument) or set the process-wide arithmetic of the shared-weight 3x3 convolutions: 'fp32' (exact fp32 products on
-    the fp32 MFMA), 'bf16x6' (3 bf16 pieces per operand, 6 products: fp32-grade), 'bf16x3' (2 pieces, 3 products, ~2^-17 per
-    product) or 'default' (back to the IDE3D_CONV_ARITH environment default).  Returns the name in force."""
+    the fp32 MFMA; the default), 'bf16x6' (3 bf16 pieces per operand, 6 products: fp32-grade), 'f16x3' (2 fp16 pieces, 3 products,
+    power-of-two range scales from the producers' `amax`: ~2^-21 per product relative to the row / image maxima), 'bf16x3' (2 bf16
+    pieces, 3 products, ~2^-17 per product) or 'default' (back to the IDE3D_CONV_ARITH environment default, else fp32).  Returns the
+    name in force.
+
+    The split arithmetics are OPT-IN.  On MI355X a wave of another kernel that executes packed fp32 VALU instructions (v_pk_fma_f32,
+    v_pk_mul_f32, v_pk_add_f32 — what hipcc / ATen emit for vectorised fp32 code) on the same SIMD beside one of these LDS-fed
+    bf16 / fp16 MFMA loops was measured to return wrong values (scripts/micro/pk_mfma_hazard.cpp).  This library
+    is built without such instructions, so its own kernels are safe next to each other; kernels of OTHER libraries (ATen
+    element-wise ops, RCCL, another tenant) running concurrently on another stream of the same GPU are not.  Select a split
+    arithmetic only where the convolutions own the GPU while they run — the render path does (one stream + its own side branch):
+    `GraphedRenderer(..., conv_arithmetic=...)`, `bench.py --conv-arith` — or build the library with -DIDE3D_SP_EXCLUSIVE_SIMD."""
     lib = load()
     if name is not None:
         _require(name in _ARITH_NAMES, f'conv_arithmetic: one of {sorted(_ARITH_NAMES)}')
         _check(lib.ide3d_set_conv_arithmetic(_ARITH_NAMES[name]), 'set_conv_arithmetic')
     code = int(lib.ide3d_get_conv_arithmetic())
-    return {1: 'fp32', 3: 'bf16x3', 6: 'bf16x6'}[code]
+    return {1: 'fp32', 3: 'bf16x3', 6: 'bf16x6', 16: 'f16x3'}[code]
 
 
 class StylePlugin:

@@ -173,6 +173,31 @@ def _styles_and_dcoefs(affine, w, weight, demodulate):
     return styles, (_demod_coefs(weight, styles) if demodulate else None)
 
 
+# ---- f16x3 arithmetic: the producers' max |y| travels with the activation -------------------------------------------------------
+# The fp16-split convolutions (hip_plugin.conv_arithmetic('f16x3')) scale their input patch by a power of two derived from a bound
+# on |x| per image.  Every fused producer on the render path (convolution epilogue, FIR epilogue) can record max |y| per image for
+# free while it stores y (`y_amax`, one atomic per wave and tile); it rides on the tensor object as `_ide3d_amax` and the consuming
+# convolution picks it up.  A tensor without it (an external caller's input, a tensor somebody modified or converted since) simply
+# makes that launch run in bf16x6.
+def _amax_wanted(x):
+    if not (x.is_cuda and x.dtype == torch.float32) or torch.is_grad_enabled():
+        return None
+    from torch_utils import hip_plugin
+    if hip_plugin.conv_arithmetic() != 'f16x3':
+        return None
+    return torch.zeros([x.shape[0], hip_plugin.AMAX_FLOATS], dtype=torch.float32, device=x.device)
+
+
+def _amax_of(x):
+    return getattr(x, '_ide3d_amax', None)
+
+
+def _with_amax(y, amax):
+    if amax is not None:
+        y._ide3d_amax = amax
+    return y
+
+
 def _modconv_init():
     global _modconv_plugin
     if _modconv_plugin is None:
@@ -330,9 +355,12 @@ def _modconv_bias_act(x, weight, styles, demodulate, noise2d, noise_strength, bi
     spec = bias_act.activation_funcs[act]
     if demodulate and dcoefs is None:
         dcoefs = _demod_coefs(weight, styles)
-    return _modconv_plugin.modconv2d(
-        x.contiguous(), weight.contiguous(), styles.contiguous(), dcoefs, noise2d, noise_strength, bias,
-        spec.cuda_idx, spec.def_alpha, gain, -1.0 if clamp is None else clamp)
+    amax = _amax_wanted(x) if kh == 3 else None
+    xc = x.contiguous()
+    return _with_amax(_modconv_plugin.modconv2d(
+        xc, weight.contiguous(), styles.contiguous(), dcoefs, noise2d, noise_strength, bias,
+        spec.cuda_idx, spec.def_alpha, gain, -1.0 if clamp is None else clamp,
+        x_amax=(_amax_of(x) if xc is x else None), y_amax=amax), amax)
 
 
 def _folded_head_weights(torgb, toseg, w):
@@ -613,15 +641,17 @@ class SynthesisLayer(torch.nn.Module):
             # up-sampling layer, MI355X inference path (same strategy as conv2d_resample.py:112-129): transposed
             # 3x3 stride-2 conv as a parity-class implicit GEMM (demodulation fused), then the 4x4 FIR with gain 4.
             dcoefs = dcoefs_pre if dcoefs_pre is not None else _demod_coefs(self.weight, styles)
-            y = _modconv_plugin.modconv2d(x.contiguous(), self.weight.contiguous(), styles.contiguous(), dcoefs,
-                                          None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
+            xc = x.contiguous()
+            y = _modconv_plugin.modconv2d(xc, self.weight.contiguous(), styles.contiguous(), dcoefs,
+                                          None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, x_amax=(_amax_of(x) if xc is x else None))
             spec = bias_act.activation_funcs[self.activation]
             if self.activation in ('linear', 'lrelu') and (noise is None or (noise.ndim == 2 and noise.shape == (2 * x.shape[2], 2 * x.shape[3]))):
                 # FIR + noise + bias + lrelu in one launch (ide3d_upfirdn2d_ex)
-                return _upfirdn_plugin().upfirdn2d_ex(y, self.resample_filter, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0,
-                                                      noise=noise, noise_strength=1.0, bias=self.bias, act=spec.cuda_idx,
-                                                      alpha=spec.def_alpha, act_gain=act_gain,
-                                                      clamp=(-1.0 if act_clamp is None else act_clamp))
+                amax = _amax_wanted(y)
+                return _with_amax(_upfirdn_plugin().upfirdn2d_ex(y, self.resample_filter, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0,
+                                                                 noise=noise, noise_strength=1.0, bias=self.bias, act=spec.cuda_idx,
+                                                                 alpha=spec.def_alpha, act_gain=act_gain,
+                                                                 clamp=(-1.0 if act_clamp is None else act_clamp), y_amax=amax), amax)
             y = upfirdn2d.upfirdn2d(y, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
             if noise is not None:
                 y = y.add_(noise)

@@ -92,6 +92,10 @@ int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* p, void* stream);
  * up-sampling SynthesisLayer, `x.add_(noise)` and `bias_act(x, b, act='lrelu', gain, clamp)` (networks.py:507-512).
  * Any pointer may be NULL; fused_act = 0 skips the bias/activation stage.  act: 1 linear, 3 lrelu.
  */
+#define IDE3D_AMAX_SLOTS  32       /* slots per image in the `amax` side outputs: workgroup b raises slot b % 32 */
+#define IDE3D_AMAX_STRIDE 64       /* floats between two slots (256 bytes: every slot in its own cache line / L2 channel) */
+#define IDE3D_AMAX_FLOATS (IDE3D_AMAX_SLOTS * IDE3D_AMAX_STRIDE)     /* floats per image; the value of slot k is element k * STRIDE */
+
 typedef struct ide3d_upfirdn2d_epilogue {
     const void*  add;
     int64_t      add_stride[4];
@@ -101,6 +105,11 @@ typedef struct ide3d_upfirdn2d_epilogue {
     int32_t      fused_act;
     int32_t      act;
     float        alpha, act_gain, clamp;
+    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 the caller zeroed: max over a row = max |finite y[n, :, :, :]| of the
+                                 finished output (every workgroup raises slot `its index % IDE3D_AMAX_SLOTS` ONCE, after a read that
+                                 usually makes the atomic unnecessary — 32 cache lines per image instead of one hot word;
+                                 non-negative floats compare like unsigned integers).
+                                 Feeds `x_amax` of the convolution that consumes y in the f16x3 arithmetic (ide3d_modconv_params). */
 } ide3d_upfirdn2d_epilogue;
 
 int ide3d_upfirdn2d_ex(const ide3d_upfirdn2d_params* p, const ide3d_upfirdn2d_epilogue* ep, void* stream);
@@ -350,7 +359,11 @@ typedef struct ide3d_modconv_params {
                                  > 0: per-image weights w + n * w_batch_stride (styles already folded in by the caller:
                                  lets heads with different styles — toRGB + toSeg, networks.py:1109,1130 — share one launch) */
     int32_t arith;            /* arithmetic of the shared-weight 3x3 layers: 0 = process default (ide3d_set_conv_arithmetic),
-                                 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (see ide3d_set_conv_arithmetic) */
+                                 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6, 16 = f16x3 (see ide3d_set_conv_arithmetic) */
+    const float* x_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS]: the row maximum is an upper bound of max |x[n, :, :, :]| (what `y_amax` of the
+                                 producing launch holds).  The f16x3 arithmetic needs it to place x * styles inside the fp16 range;
+                                 without it a launch that asked for f16x3 runs in bf16x6. */
+    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 zeroed by the caller: row maximum = max |finite y[n, :, :, :]| */
 } ide3d_modconv_params;
 
 int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,
@@ -365,8 +378,18 @@ int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
  *   6  bf16x6: each fp32 operand = 3 bf16 pieces, the 6 products above 2^-24 on v_mfma_f32_32x32x16_bf16, fp32 accumulation:
  *      fp32-grade (per-product error <= ~2^-23 relative) at 6/16 of the fp32 MFMA time;
  *   3  bf16x3: 2 pieces, 3 products, per-product error ~2^-17 relative, 3/16 of the time;
- *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3, else bf16x6 (measured against a
- *      float64 convolution its error equals the fp32 MFMA's: max 1.3e-6 vs 1.4e-6 of max |y| at 128 -> 128 @256).
+ *  16  f16x3: each operand = 2 fp16 pieces (hi = fp16(a), lo = fp16(a - hi): 22 significand bits), the 3 products hi*hi + hi*lo +
+ *      lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation: per-product error <= ~2^-21 relative to |w|max(row) * |x s|max(image),
+ *      3/16 of the fp32 MFMA time.  fp16's range is handled with exact power-of-two scales: one per weight row (from max |w[o]|,
+ *      applied when the weights are packed) and one per image (from `x_amax[n]` * max_i |styles[n, i]|, applied while the patch is
+ *      staged), both undone together with the demodulation in the epilogue.  Operands more than 2^17 below their row / image
+ *      maximum lose relative (not absolute) precision: an fp16 piece cannot be smaller than 2^-24 of the scaled range.  Needs
+ *      `x_amax`; without it the launch runs in bf16x6;
+ *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3 | f16x3, else fp32.  The split
+ *      arithmetics are opt-in: a wave of ANOTHER kernel that executes packed fp32 VALU instructions (v_pk_fma_f32 ...) on the
+ *      same SIMD beside an LDS-fed bf16 / fp16 MFMA loop was measured to return wrong results on MI355X (DESIGN.md section 4.2;
+ *      this library contains no such instructions), so a caller selects them only where no foreign kernel shares the GPU with the
+ *      convolutions — the render path does (`GeneratorSpec.conv_arithmetic`, `bench.py --conv-arith`).
  * The same switch selects the arithmetic of per-image 1x1 heads with <= 32 or 161..192 outputs on grids of >= 512 workgroups.
  * Packed weights in a modconv workspace are specific to the arithmetic they were packed for.
  */

@@ -30,7 +30,7 @@ HBM_PEAK = 8.0e12
 HBM_COPY = 6.29e12           # measured copy ceiling (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK = 157.3e12
 BF16_MFMA_PEAK = 2.5e15      # dense; the split-bf16 convolutions spend 6 (bf16x6) or 3 (bf16x3) bf16 products per fp32 product
-ARITH_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}
+ARITH_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3, 'f16x3': 3}
 N = 4                        # batch of config 2
 
 
@@ -189,12 +189,13 @@ def cases(device):
     # ---- a7 modulated convolutions (every mode) ----------------------------------------------------------------------------
     mc = hip_plugin.ModconvPlugin.modconv2d
 
-    ARITH_CODE = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6}
+    ARITH_CODE = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'f16x3': 16}
 
-    def conv_case(tag, cin, cout, res, k=3, mode=0, ariths=('bf16x6', 'fp32')):
+    def conv_case(tag, cin, cout, res, k=3, mode=0, ariths=('f16x3', 'bf16x6', 'fp32')):
         """One row per arithmetic for the layers that have a choice (3x3 stride 1 and transposed); the bound of a split-bf16 row is
         the bf16 MFMA peak / its products per fp32 product ('mfma:bf16x6' = 416.7 TFLOP/s of fp32-equivalent work)."""
         xx = rn(N, cin, res, res); ww = rn(cout, cin, k, k); ss = rn(N, cin) + 1; dc = torch.rand(N, cout, generator=g).to(device)
+        xam = xx.abs().amax(dim=(1, 2, 3))[:, None].repeat(1, 32 * 64).contiguous()          # what the producing kernel records on the render path (f16x3)
         if mode == 1:
             bz = rn(cout)
             fn = lambda: mc(xx, ww, None, None, None, 0.0, bz, 3, 0.2, math.sqrt(2), -1.0, mode=1)
@@ -205,9 +206,9 @@ def cases(device):
             code = ARITH_CODE[ar]
             if mode == 0:
                 nzz = rn(res, res); bz = rn(cout)
-                fn = lambda code=code, nzz=nzz, bz=bz: mc(xx, ww, ss, dc, nzz, 1.0, bz, 3, 0.2, math.sqrt(2), -1.0, arith=code)
+                fn = lambda code=code, nzz=nzz, bz=bz: mc(xx, ww, ss, dc, nzz, 1.0, bz, 3, 0.2, math.sqrt(2), -1.0, arith=code, x_amax=xam)
             else:
-                fn = lambda code=code: mc(xx, ww, ss, dc, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, arith=code)
+                fn = lambda code=code: mc(xx, ww, ss, dc, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, arith=code, x_amax=xam)
             kern = 'modconv_kernel' if ar == 'fp32' else 'modconv_split_kernel'
             out.append((f'{tag} [{ar}]', kern, 'mfma' if ar == 'fp32' else f'mfma:{ar}', 2 * cin * cout * k * k * res * res * N, fn))
 

@@ -205,16 +205,17 @@ def test_renderer_falls_back_for_uncompiled_decoder_width(gpu_device):
 
 def test_bench_parity_fixture_per_conv_arithmetic(bench_generator, gpu_device):
     """The frames `bench.py` counts, in every arithmetic of the 3x3 convolutions, against the oracle fixture the bench line itself
-    uses (`parity`, tests/golden/bench_parity.npz): fp32 MFMA and the default bf16x6 agree with the CPU oracle to fp32 rounding
-    (stated tolerance 2e-5 of the value range, measured 3e-6 for both); bf16x3 to 1e-4 (measured 1.4e-5)."""
+    uses (`parity`, tests/golden/bench_parity.npz): fp32 MFMA, bf16x6 and f16x3 agree with the CPU oracle to fp32 rounding
+    (stated tolerance 2e-5 of the value range, measured 3e-6); bf16x3 to 1e-4 (measured 1.4e-5)."""
     import bench
     from torch_utils import hip_plugin
     from training import triplane
     G, _sd = bench_generator
     errs = {}
     try:
-        for arith, tol in (('fp32', 2e-5), ('bf16x6', 2e-5), ('bf16x3', 1e-4)):
+        for arith, tol in (('fp32', 2e-5), ('bf16x6', 2e-5), ('f16x3', 2e-5), ('bf16x3', 1e-4)):
             hip_plugin.conv_arithmetic(arith)
+            before = hip_plugin.CALLS.get('modconv2d', 0)
             run = triplane.GraphedRenderer(G, 4, gpu_device)
             rec, _ = bench.check_parity(lambda z, c_cond, c_cam, jitter: run(z, c_cond, c_cam, jitter=jitter), gpu_device, tol=tol)
             assert rec['ok'], f'{arith}: {rec}'
@@ -222,3 +223,5 @@ def test_bench_parity_fixture_per_conv_arithmetic(bench_generator, gpu_device):
     finally:
         hip_plugin.conv_arithmetic('default')
     assert errs['bf16x6'] < 2 * errs['fp32'] + 1e-6, f'bf16x6 is not fp32-grade at frame level: {errs}'
+    assert errs['f16x3'] < 2 * errs['fp32'] + 1e-6, f'f16x3 is not fp32-grade at frame level: {errs}'
+    assert errs['f16x3'] != errs['bf16x6'], 'f16x3 must actually run (every producer on the render path hands its amax on)'
