@@ -82,7 +82,7 @@ __device__ __forceinline__ void amax_raise_block(float* amax, int n, float v, fl
     if (threadIdx.x == 0) {
         float m = scratch[0];
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, scratch[i]);
-        if (m > 0.f) amax_raise(amax, n, m);
+        if (m > 0.f) amax_raise(amax, n, m);          // (+inf included: 0x7f800000 compares above every finite pattern)
     }
 }
 // amax of a grid-stride element-wise kernel whose threads may see several images: per-workgroup maxima per image in LDS (atomic

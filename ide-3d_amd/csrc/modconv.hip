@@ -176,12 +176,10 @@ __host__ __device__ constexpr int tap_class(int t) { return (MODE == MODE_TCONV3
 // `row_unscale` / `x_unscale`: the f16x3 loop computes with weights scaled per output row and the patch scaled per image (exact powers
 // of two); both are undone here together with the demodulation (also for split-K partials, which are stored unscaled).
 // `p.y_amax` (optional): max |finished value| per image, for the consumer's f16x3 scale (wave reduction + one atomic per wave and tile).
-// running maximum of |v| over FINITE values: an inf / NaN element must not decide the scale of its whole image (its own piece
-// becomes inf / NaN in any arithmetic; the finite rest keeps its precision)
-__device__ __forceinline__ void amax_acc(float& m, float v) {
-    const float a = fabsf(v);
-    m = fmaxf(m, a < __builtin_inff() ? a : 0.f);
-}
+// running maximum of |v|: ONE v_max_f32 with the |.| source modifier per value (these epilogues are issue-bound).  A NaN does not raise
+// it (v_max returns the other operand); an inf does: the consumer then sees a non-finite bound and computes that image without range
+// scaling (f16_scale) — an image that holds an inf is broken in every arithmetic.
+__device__ __forceinline__ void amax_acc(float& m, float v) { m = fmaxf(m, fabsf(v)); }
 __device__ __forceinline__ void amax_commit(float* y_amax, int n, float v, bool) {       // several images per tile (tiny layers): per lane
     if (v > 0.f) amax_raise(y_amax, n, v);
 }

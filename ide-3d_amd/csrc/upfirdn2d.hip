@@ -144,7 +144,7 @@ upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, 
         Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3], out);
         if (ep.y_amax) {                                          // running maximum per image, flushed when the image changes
             if (n != am_n) { if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else if (am > 0.f) amax_raise(ep.y_amax, am_n, am); } am_n = n; am = 0.f; }
-            { const float a = fabsf((float)out); am = fmaxf(am, a < __builtin_inff() ? a : 0.f); }
+            am = fmaxf(am, fabsf((float)out));
         }
     }
     if (ep.y_amax) {
@@ -289,7 +289,7 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
             epilogue_row<T, NO>(row, ep, add_plane, bias, oy, ox0, p.out_w, full);
 #pragma unroll
             for (int j = 0; j < NO; ++j)
-                if (full || (ox0 + j >= 0 && ox0 + j < p.out_w)) { const float a = fabsf((float)row[j]); amax_t = fmaxf(amax_t, a < __builtin_inff() ? a : 0.f); }   // finite values only
+                if (full || (ox0 + j >= 0 && ox0 + j < p.out_w)) amax_t = fmaxf(amax_t, fabsf((float)row[j]));      // one v_max per value; NaN ignored, inf kept
             if constexpr (sizeof(T) == 4 && NO == 4) {
                 if (full && ((reinterpret_cast<uintptr_t>(yr + ox0) & 15) == 0)) {
                     float4 v4 = make_float4(row[0], row[1], row[2], row[3]);

@@ -185,7 +185,32 @@ def _amax_wanted(x):
     from torch_utils import hip_plugin
     if hip_plugin.conv_arithmetic() != 'f16x3':
         return None
+    arena = getattr(_tls, 'amax_arena', None)
+    if arena is not None and arena[1] < arena[0].shape[0] and arena[0].shape[1] == x.shape[0] and arena[0].device == x.device:
+        arena[1] += 1
+        return arena[0][arena[1] - 1]
     return torch.zeros([x.shape[0], hip_plugin.AMAX_FLOATS], dtype=torch.float32, device=x.device)
+
+
+class amax_arena:
+    """`with amax_arena(n, device):` — one zero-filled tensor for the amax side outputs of every layer of a synthesis pass (one fill
+    launch instead of one per layer; a no-op unless the f16x3 arithmetic is selected on a CUDA device)."""
+
+    def __init__(self, n, device, layers=40):
+        self.n, self.device, self.layers = n, torch.device(device), layers
+
+    def __enter__(self):
+        self.prev = getattr(_tls, 'amax_arena', None)
+        _tls.amax_arena = None
+        if self.device.type == 'cuda' and not torch.is_grad_enabled():
+            from torch_utils import hip_plugin
+            if hip_plugin.conv_arithmetic() == 'f16x3':
+                _tls.amax_arena = [torch.zeros([self.layers, self.n, hip_plugin.AMAX_FLOATS], dtype=torch.float32, device=self.device), 0]
+        return self
+
+    def __exit__(self, *exc):
+        _tls.amax_arena = self.prev
+        return False
 
 
 def _amax_of(x):

@@ -349,6 +349,8 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         prefetch = (getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled()
                     and torch.cuda.is_current_stream_capturing() and not os.environ.get('IDE3D_NO_STYLE_PREFETCH'))
         side = None
+        arena = networks.amax_arena(ws.shape[0], ws.device)
+        arena.__enter__()
         try:
             if prefetch:
                 # all style / demodulation / head-folding launches of this pass go to a side stream (they depend only on ws)
@@ -368,6 +370,7 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
                 hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
             img, seg = self.superres(feat, block_ws, **block_kwargs)
         finally:
+            arena.__exit__(None, None, None)
             if side is not None:
                 networks.finish_prefetch(side)      # joins the side stream and drops the table even when a layer raised
         img_raw = feat[:, :self.img_channels]

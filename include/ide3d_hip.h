@@ -105,8 +105,8 @@ typedef struct ide3d_upfirdn2d_epilogue {
     int32_t      fused_act;
     int32_t      act;
     float        alpha, act_gain, clamp;
-    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 the caller zeroed: max over a row = max |finite y[n, :, :, :]| of the
-                                 finished output (every workgroup raises slot `its index % IDE3D_AMAX_SLOTS` ONCE, after a read that
+    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 the caller zeroed: max over a row = max |y[n, :, :, :]| of the
+                                 finished output, NaNs ignored (every workgroup raises slot `its index % IDE3D_AMAX_SLOTS` ONCE, after a read that
                                  usually makes the atomic unnecessary — 32 cache lines per image instead of one hot word;
                                  non-negative floats compare like unsigned integers).
                                  Feeds `x_amax` of the convolution that consumes y in the f16x3 arithmetic (ide3d_modconv_params). */
@@ -363,7 +363,8 @@ typedef struct ide3d_modconv_params {
     const float* x_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS]: the row maximum is an upper bound of max |x[n, :, :, :]| (what `y_amax` of the
                                  producing launch holds).  The f16x3 arithmetic needs it to place x * styles inside the fp16 range;
                                  without it a launch that asked for f16x3 runs in bf16x6. */
-    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 zeroed by the caller: row maximum = max |finite y[n, :, :, :]| */
+    float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 zeroed by the caller: row maximum = max |y[n, :, :, :]| (NaNs ignored; an inf makes
+                                 the consumer compute that image without range scaling) */
 } ide3d_modconv_params;
 
 int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,
