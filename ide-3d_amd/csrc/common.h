@@ -62,14 +62,13 @@ __host__ __device__ __forceinline__ int floordiv(int a, int b) {
     return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
-// Raise slot (blockIdx.x % IDE3D_AMAX_SLOTS) of image n's amax row to v (v >= 0, finite): called ONCE per workgroup (callers reduce
-// inside the workgroup first).  The slot is read first (an L2 read that bypasses this CU's L1): a running maximum converges after a
-// few workgroups, so almost every call ends without the atomic.  (First version, measured: one atomic per wave on one word per image
-// = 38 ms per frame instead of 5; per-wave reads of 32 words in ONE cache line still cost 3 ms per frame.)
+// Raise slot (blockIdx.x % IDE3D_AMAX_SLOTS) of image n's amax row to v (v >= 0): called ONCE per workgroup (callers reduce inside the
+// workgroup first), a fire-and-forget atomic maximum (no return value, nothing waits for it), 32 cache lines per image.  (Measured on the
+// way here: one returning atomic per wave on one word per image = 38 ms per frame instead of 5; per-wave reads of 32 words sharing ONE
+// cache line 3 ms; a read-before-atomic per workgroup keeps the workgroup alive for an L2 round trip at its very end.)
 __device__ __forceinline__ void amax_raise(float* amax, int n, float v) {
     unsigned* const slot = reinterpret_cast<unsigned*>(amax) + (size_t)n * IDE3D_AMAX_FLOATS + (blockIdx.x % IDE3D_AMAX_SLOTS) * IDE3D_AMAX_STRIDE;
-    const unsigned bits = __float_as_uint(v);
-    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    __hip_atomic_fetch_max(slot, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Workgroup maximum of v (>= 0) through `scratch` (>= blockDim.x / 64 floats of LDS nobody else uses between the two barriers inside),
 // then one amax_raise by thread 0.  Every thread of the workgroup must call it.

@@ -620,10 +620,18 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PAR
     if constexpr (F16) {
         static_assert(PARTS == 2, "the fp16 split has two pieces");
         const f32x2 v = {a, b};
-        const f16x2 hi = __builtin_convertvector(v, f16x2);
-        const f32x2 r = {a - (float)hi.x, b - (float)hi.y};
-        const f16x2 lo = __builtin_convertvector(r, f16x2);
-        out[0] = __builtin_bit_cast(unsigned, hi); out[1] = __builtin_bit_cast(unsigned, lo);
+        const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+        // residuals a - float(hi.lo), b - float(hi.hi) in ONE instruction each: v_fma_mix_f32 reads the fp16 half directly (hipcc emits
+        // v_cvt_f32_f16 [+ SDWA] and v_sub_f32 for the plain expression: 6 instead of 4 VALU per pair in the issue-bound patch staging)
+        f32x2 r;
+#ifdef IDE3D_F16_NO_FMA_MIX
+        const f16x2 h = __builtin_bit_cast(f16x2, hi);
+        r = f32x2{a - (float)h.x, b - (float)h.y};
+#else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(hi), "v"(a));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(hi), "v"(b));
+#endif
+        out[0] = hi; out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     } else {
 #pragma unroll
     for (int q = 0; q < PARTS; ++q) {
@@ -635,6 +643,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PAR
 }
 template <int F16>
 __device__ __forceinline__ f32x16 sp_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+#ifdef IDE3D_F16_BF16MFMA        // timing experiment only (wrong results): the bf16 instruction on the fp16 pieces
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -648,6 +659,21 @@ __device__ __forceinline__ void f16_scale(float bound, float& scale, float& unsc
         e = min(max(15 - e, -126), 126);
         scale = ldexpf(1.f, e); unscale = ldexpf(1.f, -e);
     }
+}
+
+// f16x3: per-image scale of the patch from the bound max |x| (amax row of the producer) * max |style|: ONE tiny launch in front of the
+// convolution writes (scale, 1 / scale) per image; the convolution's workgroups read them with a scalar load.  (Computed inside every
+// workgroup instead — vector loads of the styles and the amax row, a shuffle reduction — this cost 22 / 26 / 51 us per launch at
+// 128 @256 / tconv 256 @128 / tconv 128 @256: a dependent L2 round trip at the head of each of up to 4096 short workgroups.)
+__global__ void __launch_bounds__(64)
+modconv_xscale_kernel(const float* __restrict__ styles, const float* __restrict__ x_amax, int cin, float* __restrict__ xscale) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float mm = styles ? 0.f : 1.f;
+    if (styles) for (int ci = lane; ci < cin; ci += 64) mm = fmaxf(mm, fabsf(styles[(int64_t)n * cin + ci]));
+    float xm = (lane < IDE3D_AMAX_SLOTS) ? x_amax[(int64_t)n * IDE3D_AMAX_FLOATS + lane * IDE3D_AMAX_STRIDE] : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mm = fmaxf(mm, __shfl_xor(mm, off)); xm = fmaxf(xm, __shfl_xor(xm, off)); }
+    if (lane == 0) { float sc, us; f16_scale(mm * xm, sc, us); xscale[2 * n] = sc; xscale[2 * n + 1] = us; }
 }
 
 // f16x3: per-row scales of the weights w [cout, rowlen]: scale[row] * max |w[row]| in [2^14, 2^15); rows >= cout: 1
@@ -708,7 +734,7 @@ __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)
 template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
                                                    const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x,
-                                                   const float* __restrict__ row_unscale) {
+                                                   const float* __restrict__ row_unscale, const float* __restrict__ xscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     static_assert(!F16 || PARTS == 2, "f16x3 = two fp16 pieces per operand");
     constexpr int PW = K::PW;
@@ -746,24 +772,9 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const float* __restrict__ ximg = p.x + (int64_t)n0 * p.cin * hw;
     float xreg[K::NXR][4];
     float sty[4];
-    // f16x3: scale of this image's patch, from the bound max |x| (p.x_amax) * max |style| (exact power of two, folded into the styles)
+    // f16x3: scale of this image's patch (exact power of two, folded into the styles), computed by modconv_xscale_kernel
     float xs = 1.f, xus = 1.f;
-    if constexpr (F16) {
-        float m = p.styles ? 0.f : 1.f;
-        if (p.styles) for (int ci = tid; ci < p.cin; ci += K::NT) m = fmaxf(m, fabsf(p.styles[(int64_t)n0 * p.cin + ci]));
-        float xm = (tid < IDE3D_AMAX_SLOTS) ? p.x_amax[(int64_t)n0 * IDE3D_AMAX_FLOATS + tid * IDE3D_AMAX_STRIDE] : 0.f;      // wave 0 holds the whole row
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off)); xm = fmaxf(xm, __shfl_xor(xm, off)); }
-        float* const red = reinterpret_cast<float*>(smem);
-        if (lane == 0) { red[wid] = m; if (wid == 0) red[NWV] = xm; }
-        __syncthreads();
-        float mm = red[0];
-#pragma unroll
-        for (int i = 1; i < NWV; ++i) mm = fmaxf(mm, red[i]);
-        xm = red[NWV];
-        __syncthreads();                                      // before the weight DMA / patch commit overwrite the scratch
-        f16_scale(mm * xm, xs, xus);
-    }
+    if constexpr (F16) { xs = xscale[2 * n0]; xus = xscale[2 * n0 + 1]; }        // wave-uniform: scalar loads
     const bool stages_patch = (NWV == 4) || wid < 4;
     auto fetch_patch = [&](int c) {
         if (!stages_patch) return;
@@ -771,7 +782,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ci = min(ci0 + k, p.cin - 1);
-            sty[k] = (ci0 + k < p.cin) ? (p.styles ? p.styles[(int64_t)n0 * p.cin + ci] : 1.f) * xs : 0.f;
+            sty[k] = (ci0 + k < p.cin) ? (p.styles ? p.styles[(int64_t)n0 * p.cin + ci] : 1.f) : 0.f;
 #pragma unroll
             for (int r = 0; r < K::NXR; ++r) xreg[r][k] = ximg[(int64_t)ci * hw + max(x_src[r], 0)];
         }
@@ -779,13 +790,17 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     auto commit_patch = [&](int buf) {
         if (!stages_patch) return;
         unsigned char* const dst = reinterpret_cast<unsigned char*>(s_x + buf * K::X_UNITS) + ((wid >> 1) * K::NSLOT) * 16 + (wid & 1) * 8;
+        // f16x3: the image scale joins the styles HERE, where the (scalar) style loads are waited for anyway — multiplied in fetch_patch it
+        // forces `s_waitcnt lgkmcnt(0)` right behind the loads, in the middle of the hand-counted operand-read pipeline (scalar loads and
+        // LDS reads share that counter): measured 10 - 30 % per launch
+        const float sc[4] = {F16 ? sty[0] * xs : sty[0], F16 ? sty[1] * xs : sty[1], F16 ? sty[2] * xs : sty[2], F16 ? sty[3] * xs : sty[3]};
 #pragma unroll
         for (int r = 0; r < K::NXR; ++r) {
             const int sidx = lane + 64 * r;
             const bool live = x_src[r] >= 0;
             unsigned lo[PARTS], hi[PARTS];
-            split_pair<PARTS, F16>(live ? xreg[r][0] * sty[0] : 0.f, live ? xreg[r][1] * sty[1] : 0.f, lo);
-            split_pair<PARTS, F16>(live ? xreg[r][2] * sty[2] : 0.f, live ? xreg[r][3] * sty[3] : 0.f, hi);
+            split_pair<PARTS, F16>(live ? xreg[r][0] * sc[0] : 0.f, live ? xreg[r][1] * sc[1] : 0.f, lo);
+            split_pair<PARTS, F16>(live ? xreg[r][2] * sc[2] : 0.f, live ? xreg[r][3] * sc[3] : 0.f, hi);
             if (sidx < K::NSLOT) {
 #pragma unroll
                 for (int q = 0; q < PARTS; ++q) {
@@ -1116,14 +1131,15 @@ constexpr int sp_waves_per_simd() {
 }
 template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4, int F16 = 0>
 __global__ void __launch_bounds__(64 * NWV, (sp_waves_per_simd<MODE, BIG, PH, PARTS, WBUF, NWV>()))
-modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
+modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale,
+                     const float* __restrict__ xscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
 #ifdef IDE3D_SP_EXCLUSIVE_SIMD
     if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255");
 #endif
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
-    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
+    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale, xscale);
 }
 
 // reduce split-K partials + epilogue
@@ -1300,7 +1316,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     if (pl.parts) {
         pl.kc = 16; pl.cchunks = cdiv(p.cin, 16);
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
-        if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
+        if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm + 2 * (int64_t)p.n;
     }
     static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
     ConvGeom& g = pl.g;
@@ -1356,20 +1372,21 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
-    const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [scale | unscale] behind the packed weights
-    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru); }
+    const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale | per-image (scale, unscale)] behind the packed weights
+    const float* xsc = F16 ? wp + pl.packed_floats + 2 * (int64_t)pl.mblocks * pl.bm : nullptr;
+    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc); }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr;
-        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
         // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6;
         // the all-class transposed form keeps 4 waves: 279 vs 268 us); IDE3D_MODCONV_SP_W4 = 4 waves everywhere
         static const bool eight = getenv("IDE3D_MODCONV_SP_W4") == nullptr && MODE == MODE_CONV3;
-        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru, xsc);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
     }
 }
 
@@ -1465,6 +1482,8 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
             else if (pl.parts == 2) hipLaunchKernelGGL(modconv_pack_split_kernel<2>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
             else               hipLaunchKernelGGL(modconv_pack_split_kernel<3>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
         }
+        if (pl.f16)
+            hipLaunchKernelGGL(modconv_xscale_kernel, dim3(p.n), dim3(64), 0, st, p.styles, p.x_amax, p.cin, wp + pl.packed_floats + 2 * (int64_t)pl.mblocks * pl.bm);
 #define IDE3D_SP_DISPATCH(M) \
         do { if (pl.big == 1) { if (pl.f16) launch_split<M, 1, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 1, 2>(p, pl, wp, partial, st); else launch_split<M, 1, 3>(p, pl, wp, partial, st); } \
              else             { if (pl.f16) launch_split<M, 2, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 2, 2>(p, pl, wp, partial, st); else launch_split<M, 2, 3>(p, pl, wp, partial, st); } } while (0)
