@@ -144,6 +144,43 @@ def test_config3_full_size_grid_frame_vs_oracle(bench_generator, gpu_device, ora
         assert flips.mean() < 5e-3, f'frame {idx}: {flips.mean():.4f} seg argmax flips'
 
 
+def test_config4_sharded_items_full_size_vs_oracle(bench_generator, gpu_device, oracle_threads):
+    """BASELINE config 4's item path where it runs (round 3): `render_grid_sharded(world=1)` at full size — 2 seeds x 8 camera poses,
+    all poses of a seed from ONE cached backbone pass, batches of 4 items, fixed per-item jitter — against oracle frames of the same
+    (seed, pose) pairs, in the default (fp32) arithmetic and in the one bench.py runs (f16x3)."""
+    from torch_utils import hip_plugin
+    from training import distributed_render as dr
+    from training import triplane
+    G, sd = bench_generator
+    seeds = [3, 11]
+    yaws = [float(y) for y in np.linspace(-0.5, 0.5, 8)]
+    osp = ospec.Spec()
+    cond = triplane.conditioning_label()
+    want = []
+    for si, seed in enumerate(seeds):
+        z = torch.from_numpy(np.random.RandomState(seed).randn(1, 512))
+        ws_o = ogen.mapping(sd, osp, z, cond, ops=fast_ops)
+        for pi, yaw in enumerate(yaws):
+            jit = torch.rand([64 * 64, 96], generator=torch.Generator().manual_seed(77 + dr.item_index(si, pi, len(yaws))))[None]
+            ref = ogen.synthesis(sd, osp, ws_o, triplane.camera_label(yaw), jitter=jit, ops=fast_ops)
+            want.append(oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0])
+    want = np.stack(want)
+    try:
+        for arith in ('fp32', 'f16x3'):
+            hip_plugin.conv_arithmetic(arith)
+            before = _calls('render_rays'), _calls('frame_u8')
+            got = dr.render_grid_sharded(G, seeds, yaws, gpu_device, rank=0, world=1, batch=4, jitter_seed=77).cpu().numpy()
+            assert _calls('render_rays') - before[0] == 4 and _calls('frame_u8') - before[1] == 4      # 16 items in batches of 4
+            assert got.shape == want.shape == (16, 512, 1024, 3)
+            for i in range(16):
+                rgb_off = np.abs(got[i, :, :512].astype(np.int32) - want[i, :, :512].astype(np.int32)) > 1
+                assert rgb_off.mean() < 5e-3, f'{arith}, item {i}: {rgb_off.mean():.4f} of the RGB values differ by more than 1 LSB'
+                flips = (got[i, :, 512:] != want[i, :, 512:]).any(axis=-1)
+                assert flips.mean() < 5e-3, f'{arith}, item {i}: {flips.mean():.4f} seg argmax flips'
+    finally:
+        hip_plugin.conv_arithmetic('default')
+
+
 def test_config5_lattice_256_and_density_vs_oracle(bench_generator, gpu_device, oracle_threads):
     """extract_shapes.py at voxel_resolution 256: the lattice, bit for bit, and the single-launch sigma cube."""
     from training import shape_extraction as se

@@ -379,3 +379,54 @@ def test_adversarial_beyond_bf16_and_non_finite_operands(gpu_device):
         assert torch.equal(bad.any(dim=1)[0], touched) and bool(bad[:, :, touched].all()), f'{name}: non-finite outputs != receptive fields of the non-finite inputs'
         e = float((y.double() - ref).abs()[:, :, ~touched].max() / ref.abs().max())
         assert e < 4e-6, f'{name}: finite outputs beside non-finite ones: {e:.2e}'
+
+
+def test_foreign_aten_kernels_beside_the_convolutions(gpu_device):
+    """kernels of OTHER libraries next to the convolutions.  Victims: ATen element-wise / reduction kernels (hipcc emits packed
+    fp32 VALU instructions for them) on stream B while stream A loops a convolution.
+      * default arithmetic (fp32 MFMA): the victims must be bit-stable — this is why fp32 is the process default;
+      * split arithmetics (opt-in): the outcome is RECORDED, not asserted (profiles/round3/aten_victims.json via gpurun_out): round 2
+        measured wrong results in packed-fp32 victims beside an LDS-fed bf16 MFMA loop; callers select a split
+        arithmetic only where no foreign kernel runs beside the convolutions, or build with -DIDE3D_SP_EXCLUSIVE_SIMD."""
+    import json, os
+    from torch_utils import hip_plugin
+    dev = gpu_device
+    assert hip_plugin.conv_arithmetic() == 'fp32'
+    g = torch.Generator().manual_seed(6)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    x = rn(4, 64, 256, 256); wt = rn(64, 64, 3, 3); s = rn(4, 64) + 1; d = torch.rand(4, 64, generator=g).to(dev)
+    xam = _finite_amax(x)
+    a, b, c = rn(1 << 22), rn(1 << 22), rn(1 << 22)
+    m1, m2 = rn(512, 512), rn(512, 512)
+    victims = {
+        'addcmul': lambda: torch.addcmul(a, b, c, value=0.5),
+        'mul_add': lambda: a * b + c,
+        'sum': lambda: (a * b).sum(),
+        'softmax': lambda: torch.softmax(m1, dim=1),
+        'matmul_fp32': lambda: m1 @ m2,
+    }
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    record = {}
+    for arith, code in (('fp32', 1), ('bf16x6', 6), ('f16x3', 16)):
+        conv = lambda: _mc()(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, arith=code, x_amax=xam)
+        with torch.cuda.stream(sa):
+            conv()
+        torch.cuda.synchronize(dev)
+        for name, fn in victims.items():
+            with torch.cuda.stream(sb):
+                ref = fn().clone()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(sa):
+                for _ in range(60):
+                    conv()
+            with torch.cuda.stream(sb):
+                outs = [fn() for _ in range(300)]
+            torch.cuda.synchronize(dev)
+            bad = sum(1 for o in outs if not torch.equal(o, ref))
+            record[f'{arith}/{name}'] = {'launches': len(outs), 'changed': bad}
+            if arith == 'fp32':
+                assert bad == 0, f'{name}: {bad} of {len(outs)} ATen launches changed beside the fp32-MFMA convolution'
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, 'aten_victims.json'), 'w') as f:
+        json.dump(record, f, indent=1)
