@@ -530,9 +530,12 @@ constexpr int PC_CAP = 504;                   // lines per buffer: 2 x (504 x 12
 #endif
 
 #ifdef IDE3D_TT_TRACE
+#ifndef IDE3D_PC_TRACE_BLOCK
+#define IDE3D_PC_TRACE_BLOCK 100
+#endif
 __device__ unsigned long long g_pc_dbg[3][32][8];
 __device__ unsigned long long g_pc_wg[1024][4];          // per workgroup (B wave 0): shader cycles entry -> end, 100 MHz clock at entry / end, staged-plane masks seen
-#define IDE3D_PCT(role, k) if (blockIdx.x == 100 && lane == 0 && ridx == 0 && it >= 0 && it < 32) g_pc_dbg[role][it][(k)] = __builtin_readcyclecounter();
+#define IDE3D_PCT(role, k) if (blockIdx.x == IDE3D_PC_TRACE_BLOCK && lane == 0 && ridx == 0 && it >= 0 && it < 32) g_pc_dbg[role][it][(k)] = __builtin_readcyclecounter();
 #else
 #define IDE3D_PCT(role, k)
 #endif
@@ -665,6 +668,8 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 unsigned char* const s_lines = s_lines0 + buf * (PC_CAP * TT_LINE);
                 Region R[3];
                 load_regions(s_reg[buf], R);
+                // (Tried: the F waves touching one dword per line of the NOT staged planes, to pull them into L1 / L2 ahead of the blending
+                // waves' buffer loads — 64 separate lines per load instruction made F the slowest role: 73.5 vs 70.3 us.)
                 int n0 = 0, n1 = 0, n2 = 0;
                 if (FR == 1) {
                     u32x4 sva[TT_SEGS_A], svb[TT_SEGS_B], svc[TT_SEGS_A];
