@@ -661,21 +661,6 @@ __device__ __forceinline__ void f16_scale(float bound, float& scale, float& unsc
     }
 }
 
-// f16x3: per-image scale of the patch from the bound max |x| (amax row of the producer) * max |style|: ONE tiny launch in front of the
-// convolution writes (scale, 1 / scale) per image; the convolution's workgroups read them with a scalar load.  (Computed inside every
-// workgroup instead — vector loads of the styles and the amax row, a shuffle reduction — this cost 22 / 26 / 51 us per launch at
-// 128 @256 / tconv 256 @128 / tconv 128 @256: a dependent L2 round trip at the head of each of up to 4096 short workgroups.)
-__global__ void __launch_bounds__(64)
-modconv_xscale_kernel(const float* __restrict__ styles, const float* __restrict__ x_amax, int cin, float* __restrict__ xscale) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    float mm = styles ? 0.f : 1.f;
-    if (styles) for (int ci = lane; ci < cin; ci += 64) mm = fmaxf(mm, fabsf(styles[(int64_t)n * cin + ci]));
-    float xm = (lane < IDE3D_AMAX_SLOTS) ? x_amax[(int64_t)n * IDE3D_AMAX_FLOATS + lane * IDE3D_AMAX_STRIDE] : 0.f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { mm = fmaxf(mm, __shfl_xor(mm, off)); xm = fmaxf(xm, __shfl_xor(xm, off)); }
-    if (lane == 0) { float sc, us; f16_scale(mm * xm, sc, us); xscale[2 * n] = sc; xscale[2 * n + 1] = us; }
-}
-
 // f16x3: per-row scales of the weights w [cout, rowlen]: scale[row] * max |w[row]| in [2^14, 2^15); rows >= cout: 1
 __global__ void __launch_bounds__(256)
 modconv_row_scale_kernel(const float* __restrict__ w, int cout, int rowlen, int rows_padded, float* __restrict__ scale, float* __restrict__ unscale) {
@@ -734,7 +719,7 @@ __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)
 template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
                                                    const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x,
-                                                   const float* __restrict__ row_unscale, const float* __restrict__ xscale) {
+                                                   const float* __restrict__ row_unscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     static_assert(!F16 || PARTS == 2, "f16x3 = two fp16 pieces per operand");
     constexpr int PW = K::PW;
@@ -772,9 +757,18 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const float* __restrict__ ximg = p.x + (int64_t)n0 * p.cin * hw;
     float xreg[K::NXR][4];
     float sty[4];
-    // f16x3: scale of this image's patch (exact power of two, folded into the styles), computed by modconv_xscale_kernel
+    // f16x3: scale of this image's patch (exact power of two, joins the styles when a patch is committed)
     float xs = 1.f, xus = 1.f;
-    if constexpr (F16) { xs = xscale[2 * n0]; xus = xscale[2 * n0 + 1]; }        // wave-uniform: scalar loads
+    if constexpr (F16) {
+        // every wave for itself (no LDS, no barrier, no extra launch): 64 lanes stride over the cin styles, lanes 0-31 read the amax
+        // slots; the result is first needed when the first patch is committed, i.e. behind that patch's own global loads
+        float mm = p.styles ? 0.f : 1.f;
+        if (p.styles) for (int ci = lane; ci < p.cin; ci += 64) mm = fmaxf(mm, fabsf(p.styles[(int64_t)n0 * p.cin + ci]));
+        float xm = (lane < IDE3D_AMAX_SLOTS) ? p.x_amax[(int64_t)n0 * IDE3D_AMAX_FLOATS + lane * IDE3D_AMAX_STRIDE] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mm = fmaxf(mm, __shfl_xor(mm, off)); xm = fmaxf(xm, __shfl_xor(xm, off)); }
+        f16_scale(mm * xm, xs, xus);
+    }
     const bool stages_patch = (NWV == 4) || wid < 4;
     auto fetch_patch = [&](int c) {
         if (!stages_patch) return;
@@ -1131,15 +1125,14 @@ constexpr int sp_waves_per_simd() {
 }
 template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4, int F16 = 0>
 __global__ void __launch_bounds__(64 * NWV, (sp_waves_per_simd<MODE, BIG, PH, PARTS, WBUF, NWV>()))
-modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale,
-                     const float* __restrict__ xscale) {
+modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
 #ifdef IDE3D_SP_EXCLUSIVE_SIMD
     if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255");
 #endif
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
-    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale, xscale);
+    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
 }
 
 // reduce split-K partials + epilogue
@@ -1316,7 +1309,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     if (pl.parts) {
         pl.kc = 16; pl.cchunks = cdiv(p.cin, 16);
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
-        if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm + 2 * (int64_t)p.n;
+        if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
     }
     static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
     ConvGeom& g = pl.g;
@@ -1372,21 +1365,20 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
-    const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale | per-image (scale, unscale)] behind the packed weights
-    const float* xsc = F16 ? wp + pl.packed_floats + 2 * (int64_t)pl.mblocks * pl.bm : nullptr;
-    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc); }
+    const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale] behind the packed weights
+    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru); }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr;
-        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
+        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
         // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6;
         // the all-class transposed form keeps 4 waves: 279 vs 268 us); IDE3D_MODCONV_SP_W4 = 4 waves everywhere
         static const bool eight = getenv("IDE3D_MODCONV_SP_W4") == nullptr && MODE == MODE_CONV3;
-        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru, xsc);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru, xsc);
+        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
 }
 
@@ -1482,8 +1474,6 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
             else if (pl.parts == 2) hipLaunchKernelGGL(modconv_pack_split_kernel<2>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
             else               hipLaunchKernelGGL(modconv_pack_split_kernel<3>, dim3(stream_grid(items, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, pl.bm, pl.mblocks, pl.cchunks, reinterpret_cast<u32x4*>(wp), nullptr);
         }
-        if (pl.f16)
-            hipLaunchKernelGGL(modconv_xscale_kernel, dim3(p.n), dim3(64), 0, st, p.styles, p.x_amax, p.cin, wp + pl.packed_floats + 2 * (int64_t)pl.mblocks * pl.bm);
 #define IDE3D_SP_DISPATCH(M) \
         do { if (pl.big == 1) { if (pl.f16) launch_split<M, 1, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 1, 2>(p, pl, wp, partial, st); else launch_split<M, 1, 3>(p, pl, wp, partial, st); } \
              else             { if (pl.f16) launch_split<M, 2, 2, 1>(p, pl, wp, partial, st); else if (pl.parts == 2) launch_split<M, 2, 2>(p, pl, wp, partial, st); else launch_split<M, 2, 3>(p, pl, wp, partial, st); } } while (0)
