@@ -27,7 +27,7 @@ def timeit(fn, iters=30):
 def round8(t):
     return (t.view(torch.int32) & ~0xFFFF).view(torch.float32)      # keep sign, exponent, 7 mantissa bits (= one bf16 piece)
 
-for tag, cin, cout, res, mode in (('3x3 128->128 @256', 128, 128, 256, 0), ('tconv 256->128 in@128', 256, 128, 128, 2), ('tconv 128->64 in@256', 128, 64, 256, 2)):
+for tag, cin, cout, res, mode in (('3x3 128->128 @256', 128, 128, 256, 0), ('3x3 256->256 @128', 256, 256, 128, 0), ('tconv 256->128 in@128', 256, 128, 128, 2), ('tconv 128->64 in@256', 128, 64, 256, 2)):
     n = 4
     for data in ('normal', 'round8', 'zeros'):
         x = torch.randn(n, cin, res, res, generator=g).to(dev); w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev)
