@@ -206,6 +206,9 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
     }
     __syncthreads();
     float* const dst = raw ? partial + (int64_t)split * p.n * p.cout * g.oh * g.ow : p.y;
+    // row pitch of the destination: the finished output may have padded rows (p.y_pitch: the (2h + 1)-wide transposed-convolution result
+    // with 16-byte aligned rows for the FIR that reads it next); split-K partials are dense
+    const int64_t pitch = (!raw && p.y_pitch > 0) ? p.y_pitch : g.ow;
     // Branch-free finish: absent terms are identities (d = 1, b = 0 in LDS; slope 1 = linear; clamp +inf; split-K partials
     // take all of them), so the 128 values of a lane do not cost four uniform branches each.
     const float e_alpha = (!raw && p.act == 3) ? p.alpha : 1.f, e_gain = raw ? 1.f : p.gain;
@@ -241,13 +244,13 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
             const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
             const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
             const bool px_ok = n < p.n && oy < g.oh && ox < g.ow, full = ox + 3 < g.ow;
-            const int64_t pofs = (int64_t)oy * g.ow + ox;
+            const int64_t pofs = (int64_t)oy * pitch + ox, nofs = (int64_t)oy * g.ow + ox;
             f32x4u nz = {0.f, 0.f, 0.f, 0.f};
             if (e_nstr != 0.f && px_ok) {
-                if (full) nz = *reinterpret_cast<const f32x4u*>(p.noise + pofs) * e_nstr;
-                else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[pofs + e] * e_nstr;
+                if (full) nz = *reinterpret_cast<const f32x4u*>(p.noise + nofs) * e_nstr;
+                else for (int e = 0; e < 4; ++e) if (ox + e < g.ow) nz[e] = p.noise[nofs + e] * e_nstr;
             }
-            float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * g.ow) + pofs;
+            float* const o_px = dst + (int64_t)n * p.cout * ((int64_t)g.oh * pitch) + pofs;
             float amax_j = 0.f;
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
@@ -269,7 +272,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
                     const float d = s_dm[ti * BM + rl], bb = s_bi[rl];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = finish(v4[e], d, nz[e], bb);
-                    float* o = o_px + (int64_t)co * ((int64_t)g.oh * g.ow);
+                    float* o = o_px + (int64_t)co * ((int64_t)g.oh * pitch);
                     if (full) {
                         *reinterpret_cast<f32x4u*>(o) = v4;
                         if (want_amax) { amax_acc(amax_j, v4[0]); amax_acc(amax_j, v4[1]); amax_acc(amax_j, v4[2]); amax_acc(amax_j, v4[3]); }
@@ -300,7 +303,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
                 const int co = mb * BM + rl;
                 if (co >= p.cout) continue;
                 const float v = finish(acc[q][i][j][r], s_dm[ti * BM + rl], nz, s_bi[rl]);
-                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * g.ow + ox) = v;
+                *(dst + (((int64_t)n * p.cout + co) * g.oh + oy) * pitch + ox) = v;
                 amax_acc(amax_j, v);
             }
         if (want_amax) { if (TI == 1) amax_tile = fmaxf(amax_tile, amax_j); else amax_commit(p.y_amax, n, amax_j, false); }
@@ -1156,7 +1159,7 @@ modconv_epilogue_kernel(ide3d_modconv_params p, const float* __restrict__ partia
         if (p.act == 3) v = (v > 0.f) ? v : v * p.alpha;
         v *= p.gain;
         if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-        p.y[i] = v;
+        if (p.y_pitch > 0) p.y[(i / ow) * p.y_pitch + (i % ow)] = v; else p.y[i] = v;        // rows of y may be padded (y_pitch)
         if (p.y_amax) {                                          // small layers only (split-K): per-thread running maximum per image
             if (n != am_n) { if (am_n >= 0) { if (am_lds) amax_lds_flush(s_am, am_n, am); else amax_commit(p.y_amax, am_n, am, false); } am_n = n; am = 0.f; }
             amax_acc(am, v);
@@ -1437,6 +1440,7 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     int rc = check_modconv(p);
     if (rc) return rc;
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
+    IDE3D_CHECK_ARG(p.y_pitch == 0 || (p.mode == 2 && p.y_pitch >= 2 * p.w_ + 1), "modconv2d: y_pitch is the row pitch of a transposed convolution's output (>= 2 w + 1), or 0");
     hipStream_t st_head = (hipStream_t)stream;
     if (head_split_applies(p, resolve_arith(p.arith))) {
         const int parts = resolve_arith(p.arith) == 3 ? 2 : 3, mt = p.cout <= 32 ? 1 : 6, cchunks = cdiv(p.cin, 16);     // f16x3: the heads stay on bf16x6

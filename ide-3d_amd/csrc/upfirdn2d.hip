@@ -216,10 +216,50 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
     const int in_y0 = (UY > 1) ? qy0 : qy0 * DY - p.pad_y0;
 
     const T* __restrict__ xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
+    // Fast staging (round 3) for fp32 planes whose rows start 16-byte aligned (row pitch a multiple of 4 floats: dense tensors of such
+    // widths, and the (2h + 1)-wide transposed-convolution output, which ide3d_modconv2d writes with padded rows for this purpose,
+    // `y_pitch`): the window is fetched with 16-byte loads from the 16-byte grid — LDS column 0 is the aligned column at or left of the
+    // window's first one (xoff = 0..3 further) — 5 loads per thread instead of 19 four-byte ones.  Elements outside the image (and the
+    // pad columns of a padded row, which hold no data) are zeroed by per-element selects on their true coordinates.
+    int xoff = 0;
+    bool staged = false;
+    if constexpr (sizeof(T) == 4 && (LH * (LW / 4) + 255) / 256 <= 16) {
+        const int64_t pitch = p.x_stride[2];
+        if ((pitch & 3) == 0 && pitch >= 4 && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)) {
+            const int x_al = in_x0 & ~3;                          // floor to the 16-byte grid (two's complement: also for negative origins)
+            xoff = in_x0 - x_al;
+            constexpr int NV = LW / 4, NLD4 = (LH * NV + 255) / 256;
+            static_assert(LW % 4 == 0 && LW >= AX::window(TCX) + 4, "LDS rows hold the window shifted by up to 3 columns");
+            float4 v4[NLD4];
+            unsigned long long okb = 0;                             // 4 validity bits per load
+#pragma unroll
+            for (int k = 0; k < NLD4; ++k) {
+                const int idx = (int)threadIdx.x + k * 256;
+                const int ly = idx / NV, lv = idx - ly * NV;
+                const int gy = in_y0 + ly, gx = x_al + 4 * lv;
+                const int cy_ = min(max(gy, 0), p.in_h - 1), cxv = min(max(gx, 0), (int)pitch - 4);
+                v4[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xp) + (int64_t)cy_ * pitch + cxv);
+                const bool rowok = (gy == cy_) && idx < LH * NV;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) okb |= (rowok && gx + e >= 0 && gx + e < p.in_w) ? (1ull << (4 * k + e)) : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < NLD4; ++k) {
+                const int idx = (int)threadIdx.x + k * 256;
+                if (idx < LH * NV) {
+                    float4 w = v4[k];
+                    w.x = ((okb >> (4 * k + 0)) & 1ull) ? w.x : 0.f; w.y = ((okb >> (4 * k + 1)) & 1ull) ? w.y : 0.f;
+                    w.z = ((okb >> (4 * k + 2)) & 1ull) ? w.z : 0.f; w.w = ((okb >> (4 * k + 3)) & 1ull) ? w.w : 0.f;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(s_in) + 4 * idx) = w;      // = row ly, columns 4 lv .. 4 lv + 3 (LW = 4 NV)
+                }
+            }
+            staged = true;
+        }
+    }
     // Stage the input window: every load is unconditional (coordinates clamped into the image, out-of-image and
     // padding elements zeroed by a select afterwards) and all of a thread's loads are issued before the first LDS
     // write — conditional loads would each sit behind their own exec-mask branch and `s_waitcnt`.
-    {
+    if (!staged) {
         constexpr int NLD = (LH * LW + 255) / 256;
         constexpr int DROW = 256 / LW, DCOL = 256 % LW;          // element i + 256 is DROW rows and DCOL columns further
         M v[NLD];
@@ -251,7 +291,7 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
     for (int wy = 0; wy < WY; ++wy)
 #pragma unroll
         for (int wx = 0; wx < WX; ++wx)
-            win[wy][wx] = s_in[(ly0 + wy) * LW + lx0 + wx];
+            win[wy][wx] = s_in[(ly0 + wy) * LW + lx0 + xoff + wx];
 
     float amax_t = 0.f;
     T* __restrict__ yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];

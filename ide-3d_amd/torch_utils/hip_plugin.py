@@ -20,7 +20,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 2
+_ABI_VERSION = 3
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -119,7 +119,7 @@ class _ModconvParams(ctypes.Structure):
         ('mode', ctypes.c_int32), ('weights_packed', ctypes.c_int32),
         ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
         ('w_batch_stride', ctypes.c_int64), ('arith', ctypes.c_int32),
-        ('x_amax', ctypes.c_void_p), ('y_amax', ctypes.c_void_p),
+        ('x_amax', ctypes.c_void_p), ('y_amax', ctypes.c_void_p), ('y_pitch', ctypes.c_int32),
     ]
 
 
@@ -746,7 +746,7 @@ class ModconvPlugin:
     _ws = {}
 
     @staticmethod
-    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0, arith=0, x_amax=None, y_amax=None):
+    def modconv2d(x, w, styles, dcoefs, noise, noise_strength, bias, act, alpha, gain, clamp, mode=0, arith=0, x_amax=None, y_amax=None, pad_rows=False):
         """arith: 0 = process default (`conv_arithmetic`), 1 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6, 16 = f16x3 (include/ide3d_hip.h).
         x_amax [n, AMAX_FLOATS]: row max = bound of max |x| per image (the f16x3 arithmetic needs it; else it runs bf16x6);
         y_amax [n, AMAX_FLOATS], zeroed: its row maxima receive max |finite y| per image.
@@ -765,7 +765,10 @@ class ModconvPlugin:
         _require(mode in (0, 1, 2), 'modconv2d: mode must be 0, 1 or 2')
         _require(mode != 1 or (k == 3 and h >= 3 and wd >= 3), 'modconv2d: mode 1 is a 3x3 stride-2 convolution on an input of at least 3x3')
         oh, ow = (2 * h + 1, 2 * wd + 1) if mode == 2 else (((h - 3) // 2 + 1, (wd - 3) // 2 + 1) if mode == 1 else (h, wd))
-        y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+        # pad_rows (mode 2): rows of the (2w + 1)-wide result padded to a multiple of 4 floats — returned as a view [..., :ow] of the padded
+        # storage — so that the FIR that reads it next stages 16-byte aligned rows
+        pitch = (ow + 3) // 4 * 4 if (pad_rows and mode == 2) else ow
+        y = torch.empty([n, cout, oh, pitch], dtype=torch.float32, device=x.device)
         lib = load()
         # one workspace per (weight, problem shape, device, launch domain): the split-K partials inside it belong to one launch at a
         # time; the domain is the current stream for eager callers and the owning GraphedRenderer inside `workspace_scope`
@@ -809,11 +812,12 @@ class ModconvPlugin:
                          f'modconv2d: {name} must be a contiguous float32 [n, AMAX_FLOATS] tensor on the device of x')
                 setattr(p, name, t.data_ptr())
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
+        p.y_pitch = pitch if pitch != ow else 0
         with torch.cuda.device(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
         ent[1], ent[2] = (None, None) if per_image else (w._version, weakref.ref(w))
-        return y
+        return y if pitch == ow else y[..., :ow]
 
 
 _ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'f16x3': 16, 'default': 0}

@@ -668,7 +668,7 @@ class SynthesisLayer(torch.nn.Module):
             dcoefs = dcoefs_pre if dcoefs_pre is not None else _demod_coefs(self.weight, styles)
             xc = x.contiguous()
             y = _modconv_plugin.modconv2d(xc, self.weight.contiguous(), styles.contiguous(), dcoefs,
-                                          None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, x_amax=(_amax_of(x) if xc is x else None))
+                                          None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, x_amax=(_amax_of(x) if xc is x else None), pad_rows=True)
             spec = bias_act.activation_funcs[self.activation]
             if self.activation in ('linear', 'lrelu') and (noise is None or (noise.ndim == 2 and noise.shape == (2 * x.shape[2], 2 * x.shape[3]))):
                 # FIR + noise + bias + lrelu in one launch (ide3d_upfirdn2d_ex)

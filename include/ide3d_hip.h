@@ -365,6 +365,9 @@ typedef struct ide3d_modconv_params {
                                  without it a launch that asked for f16x3 runs in bf16x6. */
     float*       y_amax;      /* NULL, or [n][IDE3D_AMAX_FLOATS] float32 zeroed by the caller: row maximum = max |y[n, :, :, :]| (NaNs ignored; an inf makes
                                  the consumer compute that image without range scaling) */
+    int32_t      y_pitch;     /* mode 2 only: 0 = dense y [n, cout, 2h+1, 2w+1]; else the row pitch in floats (>= 2w+1) of a y whose rows are padded —
+                                 [n, cout, 2h+1, y_pitch] storage, columns >= 2w+1 never written — so that rows start 16-byte aligned for the FIR
+                                 that consumes it (ide3d_upfirdn2d_ex stages aligned rows with 16-byte loads) */
 } ide3d_modconv_params;
 
 int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t k, int32_t mode,

@@ -95,10 +95,12 @@ def cases(device):
                             ('FIR 4x4 up2 skip 96ch 128->256', (N, 96, 128, 128), dict(up=2, padding=[2, 1, 2, 1], gain=4)),
                             ('FIR 4x4 up2 skip 22ch 256->512', (N, 22, 256, 256), dict(up=2, padding=[2, 1, 2, 1], gain=4))):
         xi = rn(*shape)
+        if shape[-1] % 4:       # the (2h + 1)-wide transposed-convolution output arrives with rows padded to a multiple of 4 floats (y_pitch)
+            xi = torch.nn.functional.pad(xi, (0, 4 - shape[-1] % 4))[..., :shape[-1]]
         yo = upfirdn2d.upfirdn2d(xi, f4, **kw)
         out.append((name, 'upfirdn2d_tile', 'hbm', (xi.numel() + yo.numel()) * 4, (lambda xi=xi, kw=kw: upfirdn2d.upfirdn2d(xi, f4, **kw))))
     # fused epilogue variant the generator runs after every transposed conv: FIR + noise + bias + lrelu
-    xi = rn(N, 64, 513, 513); nz = rn(512, 512); bb = rn(64)
+    xi = torch.nn.functional.pad(rn(N, 64, 513, 513), (0, 3))[..., :513]; nz = rn(512, 512); bb = rn(64)      # padded rows, like the tconv writes them
     upfirdn2d._init()
     out.append(('FIR 4x4 + noise/bias/lrelu 64ch 513->512', 'upfirdn2d_tile', 'hbm', (xi.numel() + N * 64 * 512 * 512) * 4,
                 lambda: upfirdn2d._plugin.upfirdn2d_ex(xi, f4, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0, noise=nz, noise_strength=1.0, bias=bb,
@@ -224,7 +226,7 @@ def cases(device):
     for cin, cout, res in ((128, 192, 256), (256, 192, 128), (64, 22, 512), (128, 22, 256)):
         xx = rn(N, cin, res, res); ww = rn(N, cout, cin, 1, 1); bz = rn(cout)
         out.append((f'dual head 1x1 (per-image weights) {cin}->{cout} @{res}', 'modconv_kernel', 'hbm', (cin + cout) * res * res * N * 4,
-                    (lambda xx=xx, ww=ww, bz=bz: mc(xx, ww, None, None, None, 0.0, bz, 1, 0.0, 1.0, 256.0))))
+                    (lambda xx=xx, ww=ww, bz=bz: mc(xx, ww, None, None, None, 0.0, bz, 1, 0.0, 1.0, 256.0, arith=16))))      # heads under f16x3 = the bf16x6 head kernel
 
     # ---- a8 style / demodulation / head folding / mapping -------------------------------------------------------------------
     networks._style_init()
