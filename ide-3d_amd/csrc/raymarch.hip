@@ -74,39 +74,217 @@ __device__ void stage_mlp(float* __restrict__ s, const float* __restrict__ w0, c
 }
 
 __device__ __forceinline__ float softplus_fast(float x) {
-    // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); abs error ~1e-7, saturates like threshold=20.
-    const float e = __expf(-fabsf(x));
-    return fmaxf(x, 0.f) + __logf(1.0f + e);
+    // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); abs error ~1e-7, saturates like threshold=20.  Raw v_exp_f32 / v_log_f32: the
+    // exponent is <= 0 (a result below the normal range is 0 beside the 1 it is added to) and the logarithm's argument is in [1, 2], so
+    // the denormal guards of __expf / __logf (a compare, a select and an ldexp each) have nothing to do here.
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * fabsf(x));
+    return fmaf(0.69314718055994530942f, __builtin_amdgcn_logf(1.0f + e), fmaxf(x, 0.f));
+}
+
+// ---- decoder MLPs on the bf16 matrix path (round 3) -----------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (1/16 of bf16): the two MLPs of a 16-sample tile are 128 of them = 4096 cycles
+// of matrix pipe per wave and tile.  With the split arithmetic of the convolutions selected (ide3d_set_conv_arithmetic != fp32) the MLPs
+// run as bf16x6 instead: every fp32 operand = 3 bf16 pieces, the 6 products above 2^-24 on v_mfma_f32_16x16x32_bf16 (K = 32 per
+// instruction: layer 1 is ONE K step, layer 2 two), fp32 accumulation — 48 instead of 128 matrix instructions per tile at ~17 instead of
+// 32 cycles each, fp32-grade products (no range to manage: bf16 has fp32's exponent).  The register layouts carry over: a lane (g, j)
+// holds channels {4 g + e} and {16 + 4 g + e} of sample j = the 8 K values of K block g under the enumeration k(g, i) = 16 (i / 4) + 4 g
+// + i % 4, and the layer-1 D registers (units 16 mt + 4 g + r) are the 8 K values of block g of K half kh = mt / 2 under
+// u(kh, g, i) = 16 (2 kh + i / 4) + 4 g + i % 4; the weights are split and stored in exactly these orders once per workgroup.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int C, int HID>
+struct RmSplit {
+    static_assert(C == 32 && HID % 32 == 0, "split MLPs: 32 input channels (one K = 32 step), hidden width a multiple of 32");
+    static constexpr int MT1 = HID / 16, KH = HID / 32;
+    static constexpr int A1 = MT1 * 3 * 64;              // 16-byte units: [mt][piece][lane]
+    static constexpr int A2 = 2 * KH * 3 * 64;           // [m2][k half][piece][lane]
+    static constexpr int BIAS = (MT1 + 2) * 16;          // floats
+    static constexpr int BYTES = (A1 + A2) * 16 + BIAS * 4;
+};
+
+// a, b -> three packed bf16 pairs (round to nearest even; the residuals are exact in fp32): low half a, high half b
+__device__ __forceinline__ void split_pair3(float a, float b, unsigned (&out)[3]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const f32x2 v = {a, b};
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        out[q] = pk;
+        if (q < 2) { a -= __uint_as_float(pk << 16); b -= __uint_as_float(pk & 0xffff0000u); }
+    }
+}
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned pk[3];
+        split_pair3(v[2 * e], v[2 * e + 1], pk);
+        out[0][e] = pk[0]; out[1][e] = pk[1]; out[2][e] = pk[2];
+    }
+}
+__device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
+    // smallest products first
+#pragma unroll
+    for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+        for (int qa = 0; qa <= sum; ++qa)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa]), __builtin_bit_cast(bf16x8, b[sum - qa]), acc, 0, 0, 0);
+    return acc;
+}
+
+template <int C, int HID>
+__device__ void stage_mlp_split(unsigned char* __restrict__ sm, const float* __restrict__ w0, const float* __restrict__ b0,
+                                const float* __restrict__ w1, const float* __restrict__ b1, int nout) {
+    using K = RmSplit<C, HID>;
+    u32x4* a1 = reinterpret_cast<u32x4*>(sm);
+    u32x4* a2 = a1 + K::A1;
+    float* sb = reinterpret_cast<float*>(a2 + K::A2);
+    for (int i = threadIdx.x; i < K::MT1 * 64; i += blockDim.x) {
+        const int lane = i & 63, mt = i >> 6, g = lane >> 4, row = 16 * mt + (lane & 15);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = w0[row * C + 16 * (k / 4) + 4 * g + k % 4];
+        u32x4 pc[3];
+        split8(v, pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a1[(mt * 3 + q) * 64 + lane] = pc[q];
+    }
+    for (int i = threadIdx.x; i < 2 * K::KH * 64; i += blockDim.x) {
+        const int lane = i & 63, kh = (i >> 6) % K::KH, m2 = i / (64 * K::KH), g = lane >> 4, row = 16 * m2 + (lane & 15);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (row < nout) ? w1[row * HID + 16 * (2 * kh + k / 4) + 4 * g + k % 4] : 0.f;
+        u32x4 pc[3];
+        split8(v, pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a2[((m2 * K::KH + kh) * 3 + q) * 64 + lane] = pc[q];
+    }
+    for (int i = threadIdx.x; i < K::MT1 * 16; i += blockDim.x) sb[i] = b0[i];                       // index = 16 mt + 4 g + r
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) sb[K::MT1 * 16 + i] = (i < nout) ? b1[i] : 0.f;
+}
+
+template <int C, int HID>
+__device__ __forceinline__ void mlp_hidden_split(const unsigned char* __restrict__ sm, const float (&f)[C / 4], f32x4 (&h)[HID / 16]) {
+    using K = RmSplit<C, HID>;
+    const int lane = lane_id(), g = lane >> 4;
+    const u32x4* a1 = reinterpret_cast<const u32x4*>(sm);
+    const f32x4* sb0 = reinterpret_cast<const f32x4*>(sm + (K::A1 + K::A2) * 16);
+    u32x4 fb[3];
+    split8(f, fb);
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt) {
+        const u32x4 a[3] = {a1[(mt * 3 + 0) * 64 + lane], a1[(mt * 3 + 1) * 64 + lane], a1[(mt * 3 + 2) * 64 + lane]};
+        h[mt] = mfma6(a, fb, sb0[mt * 4 + g]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mt][r] = softplus_fast(h[mt][r]);
+}
+
+template <int C, int HID>
+__device__ __forceinline__ void mlp_tile_split(const unsigned char* __restrict__ sm, const float (&f)[C / 4], f32x4 (&out)[2]) {
+    using K = RmSplit<C, HID>;
+    const int lane = lane_id(), g = lane >> 4;
+    const u32x4* a2 = reinterpret_cast<const u32x4*>(sm) + K::A1;
+    const f32x4* sb1 = reinterpret_cast<const f32x4*>(sm + (K::A1 + K::A2) * 16) + K::MT1 * 4;
+    f32x4 h[K::MT1];
+    mlp_hidden_split<C, HID>(sm, f, h);
+    u32x4 hb[K::KH][3];
+#pragma unroll
+    for (int kh = 0; kh < K::KH; ++kh) {
+        const float v[8] = {h[2 * kh][0], h[2 * kh][1], h[2 * kh][2], h[2 * kh][3], h[2 * kh + 1][0], h[2 * kh + 1][1], h[2 * kh + 1][2], h[2 * kh + 1][3]};
+        split8(v, hb[kh]);
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+        f32x4 acc = sb1[m2 * 4 + g];
+#pragma unroll
+        for (int kh = 0; kh < K::KH; ++kh) {
+            const int o = ((m2 * K::KH + kh) * 3) * 64 + lane;
+            const u32x4 a[3] = {a2[o], a2[o + 64], a2[o + 128]};
+            acc = mfma6(a, hb[kh], acc);
+        }
+        out[m2] = acc;
+    }
+}
+
+// (density only, split form) hidden layer on the bf16 matrix path, row 0 of the second layer as a VALU dot product like mlp_sigma
+template <int C, int HID>
+__device__ __forceinline__ float mlp_sigma_split(const unsigned char* __restrict__ sm, const float* __restrict__ s_row, const float (&f)[C / 4]) {
+    using K = RmSplit<C, HID>;
+    const int g = lane_id() >> 4;
+    f32x4 h[K::MT1];
+    mlp_hidden_split<C, HID>(sm, f, h);
+    float acc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < K::MT1; ++mt) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(s_row + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += w[r] * h[mt][r];
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    return acc + s_row[HID];
 }
 
 // Gather this lane's NF features of one sample from one tri-plane (channels_last, channel stride 1).
+// Lane layouts.  The matrix instructions want lane 16 g + j to hold K block g of sample (column) j: neighbouring lanes are
+// DIFFERENT samples.  Gathering in that layout makes every lane of a 16-byte load its own cache-line access (16 useful bytes per L1
+// access; 64 accesses per instruction; the kernel then runs at exactly the L1 access rate: 2 tri-planes x 12 taps x 8 accesses per
+// sample = 0.49 ms for the 1.57 M samples of the benchmark pass, measured 0.50 — round 3).  So the gathers run in a second layout,
+// lane 4 j + g (`gather layout`: four neighbouring lanes read 64 contiguous bytes of one tap of one sample — one access), each lane
+// blends its 16-byte slices with the tap weights of sample lane / 4, and the blended features — 8 values per lane and tri-plane —
+// change lanes once (ds_bpermute, no memory) into the matrix layout.
+__device__ __forceinline__ int gather_sample(int lane) { return lane >> 2; }
+__device__ __forceinline__ int gather_block(int lane) { return lane & 3; }
+
+template <int NF>
+__device__ __forceinline__ void to_matrix_lanes(float (&f)[NF]) {
+    const int lane = lane_id();
+    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;        // lane 16 g + j reads lane 4 j + g (byte address of its dword)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) f[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f[i])));
+}
+
+// `t`: taps of sample gather_sample(lane); `g` = gather_block(lane).  Result in the gather layout (f[4 ci + e] = channel
+// 16 ci + 4 g + e of that sample): follow with to_matrix_lanes.
 template <int C>
 __device__ __forceinline__ void gather_features(const float* __restrict__ pb, const TapAddr (&t)[3], int g, float (&f)[C / 4]) {
     constexpr int CPL = C / 16;
+    // Every 16-byte tap load of the sample — 12 per channel slice, all CPL slices — is issued before the first one is consumed.  The
+    // renderer is bound by the bytes it keeps in flight (8 waves per CU, a loaded L2 round trip of ~2 us: with 12 loads per wave in
+    // flight the whole chip moves ~10 TB/s of taps and the kernel takes exactly the time of its gathers, MLPs or not — round-3
+    // measurement), so the load buffer is as large as the register budget allows: 48 * CPL registers, free again
+    // before the MLP starts.  Left to itself the compiler loads a plane's four taps, waits, blends.
+    float4 v[CPL][3][4];
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
         const int ch = 4 * (g + 4 * ci);
-        // all twelve 16-byte tap loads of this channel slice are issued before the first one is consumed: left to itself
-        // the compiler loads a plane's four taps, waits, blends, and so exposes the L2 latency three times per slice
-        float4 v[3][4];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const float* base = pb + pl * C + ch;
-            v[pl][0] = ld4(base + t[pl].o00); v[pl][1] = ld4(base + t[pl].o01);
-            v[pl][2] = ld4(base + t[pl].o10); v[pl][3] = ld4(base + t[pl].o11);
+            v[ci][pl][0] = ld4(base + t[pl].o00); v[ci][pl][1] = ld4(base + t[pl].o01);
+            v[ci][pl][2] = ld4(base + t[pl].o10); v[ci][pl][3] = ld4(base + t[pl].o11);
         }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(v[pl][k].x), "+v"(v[pl][k].y), "+v"(v[pl][k].z), "+v"(v[pl][k].w));
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(v[ci][pl][k].x), "+v"(v[ci][pl][k].y), "+v"(v[ci][pl][k].z), "+v"(v[ci][pl][k].w));
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
         float4 a[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = f4_fma(v[pl][0], t[pl].w00, acc);
-            acc = f4_fma(v[pl][1], t[pl].w01, acc);
-            acc = f4_fma(v[pl][2], t[pl].w10, acc);
-            acc = f4_fma(v[pl][3], t[pl].w11, acc);
+            acc = f4_fma(v[ci][pl][0], t[pl].w00, acc);
+            acc = f4_fma(v[ci][pl][1], t[pl].w01, acc);
+            acc = f4_fma(v[ci][pl][2], t[pl].w10, acc);
+            acc = f4_fma(v[ci][pl][3], t[pl].w11, acc);
             a[pl] = acc;
         }
         f[4 * ci + 0] = (a[0].x + a[1].x) + a[2].x;
@@ -202,15 +380,30 @@ __device__ __forceinline__ float seg16_excl_prod(float v, float& total) {
     return j == 0 ? 1.0f : prev;
 }
 
-template <int C, int HID>
+// MLP storage of one decoder branch in LDS, by arithmetic (SPLIT: bf16x6 on v_mfma_f32_16x16x32_bf16; else fp32 MFMA)
+template <int C, int HID, bool SPLIT> struct MlpBytes { static constexpr int value = RmCfg<C, HID>::MLP * 4; };
+template <int C, int HID> struct MlpBytes<C, HID, true> { static constexpr int value = RmSplit<C, HID>::BYTES; };
+
+template <int C, int HID, bool SPLIT>
+__device__ __forceinline__ void stage_branch(unsigned char* sm, const float* w0, const float* b0, const float* w1, const float* b1, int nout) {
+    if constexpr (SPLIT) stage_mlp_split<C, HID>(sm, w0, b0, w1, b1, nout);
+    else stage_mlp<C, HID>(reinterpret_cast<float*>(sm), w0, b0, w1, b1, nout);
+}
+template <int C, int HID, bool SPLIT>
+__device__ __forceinline__ void mlp_branch(const unsigned char* sm, const float (&f)[C / 4], f32x4 (&out)[2]) {
+    if constexpr (SPLIT) mlp_tile_split<C, HID>(sm, f, out);
+    else mlp_tile<C, HID>(reinterpret_cast<const float*>(sm), f, out);
+}
+
+template <int C, int HID, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     using K = RmCfg<C, HID>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_geo = lds;
-    float* s_tex = lds + K::MLP;
-    stage_mlp<C, HID>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
-    stage_mlp<C, HID>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
+    unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* s_tex = s_geo + MlpBytes<C, HID, SPLIT>::value;
+    stage_branch<C, HID, SPLIT>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
+    stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
     __syncthreads();
 
     const int lane = lane_id(), wid = threadIdx.x >> 6;
@@ -245,34 +438,45 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
         float carry = 1.0f, wsum = 0.f, dsum = 0.f;
 
         for (int s0 = 0; s0 < S; s0 += 16) {
+            // --- gather layout: position of sample s0 + lane / 4 (camera space -> jitter -> world) and its taps ---
+            TapAddr t[3];
+            {
+                const int sl = min(s0 + gather_sample(lane), S - 1);
+                const float zl = p.z_lin[sl];
+                float px = __fmul_rn(dx, zl), py = __fmul_rn(dy, zl), pz = __fmul_rn(dz, zl);
+                if (jit) {
+                    const float off = __fmul_rn(__fsub_rn(jit[sl], 0.5f), zstep);
+                    px = __fadd_rn(px, __fmul_rn(off, dx));
+                    py = __fadd_rn(py, __fmul_rn(off, dy));
+                    pz = __fadd_rn(pz, __fmul_rn(off, dz));
+                }
+                const float wx = fmaf(m00, px, fmaf(m01, py, fmaf(m02, pz, m03)));
+                const float wy = fmaf(m10, px, fmaf(m11, py, fmaf(m12, pz, m13)));
+                const float wz = fmaf(m20, px, fmaf(m21, py, fmaf(m22, pz, m23)));
+                t[0] = make_tap_addr(wx, wy, p.W, p.H, sH, sW);
+                t[1] = make_tap_addr(wy, wz, p.W, p.H, sH, sW);
+                t[2] = make_tap_addr(wx, wz, p.W, p.H, sH, sW);
+            }
+            // --- matrix layout: depth of sample s0 + lane % 16 for the compositing ---
             const int s = s0 + j;
             const bool live = s < S;
             const int sc = live ? s : S - 1;
-            // --- sample position (camera space -> jitter -> world) ---
             float z = p.z_lin[sc];
-            float px = __fmul_rn(dx, z), py = __fmul_rn(dy, z), pz = __fmul_rn(dz, z);
             float znext = (sc + 1 < S) ? p.z_lin[sc + 1] : 0.f;
             if (jit) {
-                const float off = __fmul_rn(__fsub_rn(jit[sc], 0.5f), zstep);
-                z = __fadd_rn(z, off);
-                px = __fadd_rn(px, __fmul_rn(off, dx));
-                py = __fadd_rn(py, __fmul_rn(off, dy));
-                pz = __fadd_rn(pz, __fmul_rn(off, dz));
+                z = __fadd_rn(z, __fmul_rn(__fsub_rn(jit[sc], 0.5f), zstep));
                 if (sc + 1 < S) znext = __fadd_rn(znext, __fmul_rn(__fsub_rn(jit[sc + 1], 0.5f), zstep));
             }
-            const float wx = fmaf(m00, px, fmaf(m01, py, fmaf(m02, pz, m03)));
-            const float wy = fmaf(m10, px, fmaf(m11, py, fmaf(m12, pz, m13)));
-            const float wz = fmaf(m20, px, fmaf(m21, py, fmaf(m22, pz, m23)));
-            // --- gathers ---
-            const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
-                                   make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
+            const int gl = gather_block(lane);
             float fg[K::NF], ft[K::NF];
             f32x4 og[2], ot[2];
-            gather_features<C>(geo_b, t, g, fg);
-            mlp_tile<C, HID>(s_geo, fg, og);
+            gather_features<C>(geo_b, t, gl, fg);
+            to_matrix_lanes(fg);
+            mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
             asm volatile("" ::: "memory");     // keep the second gather behind the first MLP (register budget)
-            gather_features<C>(tex_b, t, g, ft);
-            mlp_tile<C, HID>(s_tex, ft, ot);
+            gather_features<C>(tex_b, t, gl, ft);
+            to_matrix_lanes(ft);
+            mlp_branch<C, HID, SPLIT>(s_tex, ft, ot);
             // --- compositing weights ---
             float sigma = __shfl(og[0][0], j);                    // feature 0 lives in lanes g = 0
             if (sgn) sigma += sgn[sc];
@@ -356,18 +560,22 @@ __global__ void lattice_points_kernel(Src src, int64_t count, float* __restrict_
 }
 
 // sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
-template <int C, int HID, class Src>
-__global__ void __launch_bounds__(256, 2)
+#ifndef IDE3D_VOX_LB
+#define IDE3D_VOX_LB 2
+#endif
+template <int C, int HID, class Src, bool SPLIT>
+__global__ void __launch_bounds__(256, IDE3D_VOX_LB)
 sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
                     float* __restrict__ out, float* __restrict__ out_sigma, int sigma_only, int64_t tiles_per_block) {
     using K = RmCfg<C, HID>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_geo = lds;
-    float* s_tex = lds + K::MLP;
-    float* s_stage = lds + 2 * K::MLP;                 // [4 waves][16 samples][width] row staging
-    stage_mlp<C, HID>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
-    if (!sigma_only) stage_mlp<C, HID>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
-    float* const s_row = s_tex;                        // sigma-only: row 0 of geo_w1 + its bias live where the texture MLP would
+    constexpr int MB = MlpBytes<C, HID, SPLIT>::value;
+    unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* s_tex = s_geo + MB;
+    float* s_stage = reinterpret_cast<float*>(s_geo + 2 * MB);                 // [4 waves][16 samples][width] row staging
+    stage_branch<C, HID, SPLIT>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
+    if (!sigma_only) stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
+    float* const s_row = reinterpret_cast<float*>(s_tex);                        // sigma-only: row 0 of geo_w1 + its bias live where the texture MLP would
     if (sigma_only) {
         for (int i = threadIdx.x; i <= HID; i += blockDim.x) s_row[i] = (i < HID) ? p.geo_w1[i] : p.geo_b1[0];
     }
@@ -387,25 +595,32 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
         const int64_t row0 = tile * 16;
         const int64_t row = row0 + j;
         const bool live = row < rows;
-        const int64_t rc = live ? row : rows - 1;
+        // gather layout (lane 4 j + g): the point and the taps of row row0 + lane / 4
+        const int64_t rl = row0 + gather_sample(lane);
+        const int64_t rc = rl < rows ? rl : rows - 1;
         const int n = (int)(rc / m);
+        const int gl = gather_block(lane);
         float wx, wy, wz;
         src.get(rc, m, wx, wy, wz);
         const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
                                make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
         float fg[K::NF];
-        gather_features<C>(p.geo_planes + n * p.geo_stride[0], t, g, fg);
+        gather_features<C>(p.geo_planes + n * p.geo_stride[0], t, gl, fg);
+        to_matrix_lanes(fg);
         if (sigma_only) {
-            const float sig = mlp_sigma<C, HID>(s_geo, s_row, fg);
+            float sig;
+            if constexpr (SPLIT) sig = mlp_sigma_split<C, HID>(s_geo, s_row, fg);
+            else sig = mlp_sigma<C, HID>(reinterpret_cast<const float*>(s_geo), s_row, fg);
             if (g == 0 && live) out_sigma[row] = sig;
             continue;
         }
         f32x4 og[2];
-        mlp_tile<C, HID>(s_geo, fg, og);
+        mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
         float ft[K::NF];
-        gather_features<C>(p.tex_planes + n * p.tex_stride[0], t, g, ft);
+        gather_features<C>(p.tex_planes + n * p.tex_stride[0], t, gl, ft);
+        to_matrix_lanes(ft);
         f32x4 ot[2];
-        mlp_tile<C, HID>(s_tex, ft, ot);
+        mlp_branch<C, HID, SPLIT>(s_tex, ft, ot);
         // stage the 16 x width row block, then write it out contiguously
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -426,34 +641,32 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     }
 }
 
-template <int C, int HID>
+template <int C, int HID, bool SPLIT = false>
 static int launch_render(const ide3d_render_params& p, hipStream_t st) {
-    using K = RmCfg<C, HID>;
-    const size_t lds_bytes = (size_t)2 * K::MLP * sizeof(float);
+    const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value;
     const int64_t total_rays = (int64_t)p.n * p.rays_per_img;
     int64_t nblk = kNumCU * 2;
     int64_t rpb = cdiv64(cdiv64(total_rays, nblk), 4) * 4;
     if (rpb < 4) rpb = 4;
     nblk = cdiv64(total_rays, rpb);
-    auto kern = render_rays_kernel<C, HID>;
+    auto kern = render_rays_kernel<C, HID, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, rpb);
     IDE3D_CHECK_LAUNCH("render_rays");
     return IDE3D_OK;
 }
 
-template <int C, int HID, class Src>
+template <int C, int HID, class Src, bool SPLIT = false>
 static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m, float* out, float* out_sigma,
                         int sigma_only, hipStream_t st) {
-    using K = RmCfg<C, HID>;
     const int width = p.feat_ch + p.seg_ch + 1;
-    const size_t lds_bytes = ((size_t)2 * K::MLP + (size_t)4 * 16 * width) * sizeof(float);
+    const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value + (size_t)4 * 16 * width * sizeof(float);
     const int64_t ntiles = cdiv64((int64_t)p.n * m, 16);
     int64_t nblk = kNumCU * 2;
     int64_t tpb = cdiv64(cdiv64(ntiles, nblk), 4) * 4;
     if (tpb < 4) tpb = 4;
     nblk = cdiv64(ntiles, tpb);
-    auto kern = sample_voxel_kernel<C, HID, Src>;
+    auto kern = sample_voxel_kernel<C, HID, Src, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out, out_sigma, sigma_only, tpb);
     IDE3D_CHECK_LAUNCH("sample_voxel");
@@ -487,6 +700,10 @@ static bool planes_fast(const ide3d_render_params& p) {
 
 }  // namespace ide3d
 
+// The decoder MLPs follow the arithmetic selected for the convolutions (ide3d_set_conv_arithmetic, modconv.hip): exact fp32 products on
+// the fp32 matrix path by default, bf16x6 (fp32-grade) with any of the split arithmetics.
+static bool mlp_split_selected() { return ide3d_get_conv_arithmetic() != 1; }
+
 extern "C" int ide3d_render_rays(const ide3d_render_params* pp, void* stream) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(pp != nullptr, "render_rays: null params");
@@ -496,7 +713,7 @@ extern "C" int ide3d_render_rays(const ide3d_render_params* pp, void* stream) {
     if (p.last_back) { set_error("render_rays: last_back is not fused; use the step-wise ops"); return IDE3D_ENOKERNEL; }
     if (!planes_fast(p)) { set_error("render_rays: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
-    if (p.C == 32 && p.hidden == 64) return launch_render<32, 64>(p, st);
+    if (p.C == 32 && p.hidden == 64) return mlp_split_selected() ? launch_render<32, 64, true>(p, st) : launch_render<32, 64>(p, st);
     if (p.C == 16 && p.hidden == 32) return launch_render<16, 32>(p, st);
     set_error("render_rays: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
     return IDE3D_ENOKERNEL;
@@ -515,7 +732,8 @@ extern "C" int ide3d_sample_voxel(const ide3d_render_params* pp, const float* pt
     if (!planes_fast(p)) { set_error("sample_voxel: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     const PointsFromMemory src{pts};
-    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, src, m, out, out_sigma, sigma_only, st);
+    if (p.C == 32 && p.hidden == 64) return mlp_split_selected() ? launch_voxel<32, 64, PointsFromMemory, true>(p, src, m, out, out_sigma, sigma_only, st)
+                                                                  : launch_voxel<32, 64>(p, src, m, out, out_sigma, sigma_only, st);
     if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, src, m, out, out_sigma, sigma_only, st);
     set_error("sample_voxel: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
     return IDE3D_ENOKERNEL;
@@ -556,7 +774,8 @@ extern "C" int ide3d_density_lattice(const ide3d_render_params* pp, const ide3d_
     if (!planes_fast(p)) { set_error("density_lattice: tri-planes must be channels_last, 16-byte aligned"); return IDE3D_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     const PointsFromLattice src{*lat, first};
-    if (p.C == 32 && p.hidden == 64) return launch_voxel<32, 64>(p, src, count, nullptr, out_sigma, 1, st);
+    if (p.C == 32 && p.hidden == 64) return mlp_split_selected() ? launch_voxel<32, 64, PointsFromLattice, true>(p, src, count, nullptr, out_sigma, 1, st)
+                                                                  : launch_voxel<32, 64>(p, src, count, nullptr, out_sigma, 1, st);
     if (p.C == 16 && p.hidden == 32) return launch_voxel<16, 32>(p, src, count, nullptr, out_sigma, 1, st);
     set_error("density_lattice: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
     return IDE3D_ENOKERNEL;
