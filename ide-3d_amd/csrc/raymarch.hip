@@ -106,13 +106,24 @@ struct RmSplit {
 };
 
 // a, b -> three packed bf16 pairs (round to nearest even; the residuals are exact in fp32): low half a, high half b
+// The residuals come from v_dot2c_f32_bf16: x - hi = dot((hi_a, hi_b), (-1, 0)) + x, one instruction per value instead of an unpack and
+// a subtraction (exact: scripts/micro/split_dot2_check.hip compares the pieces of 2^24 values bit for bit with the mask / subtract form).
 __device__ __forceinline__ void split_pair3(float a, float b, unsigned (&out)[3]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const f32x2 v = {a, b};
-        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        out[q] = pk;
-        if (q < 2) { a -= __uint_as_float(pk << 16); b -= __uint_as_float(pk & 0xffff0000u); }
+        const bf16x2 pk = __builtin_convertvector(v, bf16x2);
+        out[q] = __builtin_bit_cast(unsigned, pk);
+#if defined(IDE3D_SPLIT_NO_DOT2)
+        if (q < 2) { a -= __uint_as_float(out[q] << 16); b -= __uint_as_float(out[q] & 0xffff0000u); }
+#else
+        // (the multipliers go through scalar registers: as immediates hipcc emits the inline constant -1.0 for (-1, 0), which the instruction
+        // does not read as bf16 (-1, 0))
+        unsigned clo = 0x0000bf80u, chi = 0xbf800000u;
+        asm volatile("" : "+s"(clo), "+s"(chi));
+        const bf16x2 mlo = __builtin_bit_cast(bf16x2, clo), mhi = __builtin_bit_cast(bf16x2, chi);
+        if (q < 2) { a = __builtin_amdgcn_fdot2_f32_bf16(pk, mlo, a, false); b = __builtin_amdgcn_fdot2_f32_bf16(pk, mhi, b, false); }
+#endif
     }
 }
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
@@ -248,43 +259,63 @@ __device__ __forceinline__ void to_matrix_lanes(float (&f)[NF]) {
     for (int i = 0; i < NF; ++i) f[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f[i])));
 }
 
-// `t`: taps of sample gather_sample(lane); `g` = gather_block(lane).  Result in the gather layout (f[4 ci + e] = channel
-// 16 ci + 4 g + e of that sample): follow with to_matrix_lanes.
+template <int C> struct TapBuf { float4 v[C / 16][3][4]; };
+
+// a global-memory address known to be the same in every lane -> scalar registers (what the scalar-base load form needs)
+typedef const __attribute__((address_space(1))) char* GlobalBytes;
+template <class T>
+__device__ __forceinline__ GlobalBytes uniform_ptr(const T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<GlobalBytes>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float4 ld4_at(GlobalBytes base, unsigned byte_off, unsigned imm) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) v4f* GlobalF4;
+    const v4f v = *reinterpret_cast<GlobalF4>(base + (size_t)byte_off + imm);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 template <int C>
-__device__ __forceinline__ void gather_features(const float* __restrict__ pb, const TapAddr (&t)[3], int g, float (&f)[C / 4]) {
+__device__ __forceinline__ void issue_taps(GlobalBytes pbc, const TapAddr (&t)[3], int g, TapBuf<C>& b, unsigned lane_extra = 0) {
     constexpr int CPL = C / 16;
-    // Every 16-byte tap load of the sample — 12 per channel slice, all CPL slices — is issued before the first one is consumed.  The
-    // renderer is bound by the bytes it keeps in flight (8 waves per CU, a loaded L2 round trip of ~2 us: with 12 loads per wave in
-    // flight the whole chip moves ~10 TB/s of taps and the kernel takes exactly the time of its gathers, MLPs or not — round-3
-    // measurement), so the load buffer is as large as the register budget allows: 48 * CPL registers, free again
-    // before the MLP starts.  Left to itself the compiler loads a plane's four taps, waits, blends.
-    float4 v[CPL][3][4];
+    // Every 16-byte tap load of the sample — 12 per channel slice, all CPL slices — is issued before the first one is consumed; left
+    // to itself the compiler loads a plane's four taps, waits, blends.
+    // `pb` is wave-uniform and the tap offsets are unsigned 32-bit byte counts (planes_fast bounds them), so every load is the
+    // scalar-base form — global_load_dwordx4 v, v_off, s[base:base+1] offset:imm — with the plane / slice part in the immediate: no
+    // 64-bit address arithmetic per tap.
+    const unsigned lane_b = 16u * (unsigned)g + lane_extra;          // lane_extra: a per-lane byte offset on top (an image further on)
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
-        const int ch = 4 * (g + 4 * ci);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            const float* base = pb + pl * C + ch;
-            v[ci][pl][0] = ld4(base + t[pl].o00); v[ci][pl][1] = ld4(base + t[pl].o01);
-            v[ci][pl][2] = ld4(base + t[pl].o10); v[ci][pl][3] = ld4(base + t[pl].o11);
+            const unsigned imm = (unsigned)(pl * C + 16 * ci) * 4u;
+            b.v[ci][pl][0] = ld4_at(pbc, (unsigned)t[pl].o00 * 4u + lane_b, imm); b.v[ci][pl][1] = ld4_at(pbc, (unsigned)t[pl].o01 * 4u + lane_b, imm);
+            b.v[ci][pl][2] = ld4_at(pbc, (unsigned)t[pl].o10 * 4u + lane_b, imm); b.v[ci][pl][3] = ld4_at(pbc, (unsigned)t[pl].o11 * 4u + lane_b, imm);
         }
     }
+}
+
+template <int C>
+__device__ __forceinline__ void blend_taps(TapBuf<C>& b, const TapAddr (&t)[3], float (&f)[C / 4]) {
+    constexpr int CPL = C / 16;
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(v[ci][pl][k].x), "+v"(v[ci][pl][k].y), "+v"(v[ci][pl][k].z), "+v"(v[ci][pl][k].w));
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(b.v[ci][pl][k].x), "+v"(b.v[ci][pl][k].y), "+v"(b.v[ci][pl][k].z), "+v"(b.v[ci][pl][k].w));
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
         float4 a[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = f4_fma(v[ci][pl][0], t[pl].w00, acc);
-            acc = f4_fma(v[ci][pl][1], t[pl].w01, acc);
-            acc = f4_fma(v[ci][pl][2], t[pl].w10, acc);
-            acc = f4_fma(v[ci][pl][3], t[pl].w11, acc);
+            acc = f4_fma(b.v[ci][pl][0], t[pl].w00, acc);
+            acc = f4_fma(b.v[ci][pl][1], t[pl].w01, acc);
+            acc = f4_fma(b.v[ci][pl][2], t[pl].w10, acc);
+            acc = f4_fma(b.v[ci][pl][3], t[pl].w11, acc);
             a[pl] = acc;
         }
         f[4 * ci + 0] = (a[0].x + a[1].x) + a[2].x;
@@ -292,6 +323,15 @@ __device__ __forceinline__ void gather_features(const float* __restrict__ pb, co
         f[4 * ci + 2] = (a[0].z + a[1].z) + a[2].z;
         f[4 * ci + 3] = (a[0].w + a[1].w) + a[2].w;
     }
+}
+
+// `t`: taps of sample gather_sample(lane); `g` = gather_block(lane).  Result in the gather layout (f[4 ci + e] = channel
+// 16 ci + 4 g + e of that sample): follow with to_matrix_lanes.
+template <int C>
+__device__ __forceinline__ void gather_features(const float* __restrict__ pb, const TapAddr (&t)[3], int g, float (&f)[C / 4]) {
+    TapBuf<C> b;
+    issue_taps<C>(uniform_ptr(pb), t, g, b);
+    blend_taps<C>(b, t, f);
 }
 
 // Two-layer MLP on a 16-sample tile, transposed MFMA form.  out[mt][r] = feature 16 mt + 4 g + r of sample j.
@@ -406,8 +446,8 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
     __syncthreads();
 
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
-    const int g = lane >> 4, j = lane & 15;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15, gl = gather_block(lane);
     const int64_t total_rays = (int64_t)p.n * p.rays_per_img;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t ray_begin = (int64_t)blk * rays_per_block;
@@ -416,119 +456,166 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     const int S = p.steps;
     const int nch = p.feat_ch + p.seg_ch;
     const int sH = (int)p.tex_stride[2], sW = (int)p.tex_stride[3];   // host guarantees tex / geo share the layout
+    const float zstep = (S > 1) ? (p.z_lin[1] - p.z_lin[0]) : 0.f;
 
-    for (int64_t ray = ray_begin + wid; ray < ray_end; ray += 4) {
-        const int n = (int)(ray / p.rays_per_img);
-        const int r = (int)(ray - (int64_t)n * p.rays_per_img);
+    // Depth of sample s0 + lane / 4 of `ray` (gather layout): the two small loads the tap addresses hang on, issued one tile ahead.
+    auto tile_depth = [&](int64_t ray, int s0, float& zl, float& jl) {
+        const int sl = min(s0 + gather_sample(lane), S - 1);
+        zl = p.z_lin[sl];
+        jl = p.jitter ? p.jitter[ray * S + sl] : 0.5f;
+    };
+    // Taps of that sample: camera space -> jitter -> world.  Everything per ray is wave-uniform (scalar loads), so a tile of the NEXT
+    // ray costs the same as one of this ray.
+    auto tile_taps = [&](int n, int r, float zl, float jl, TapAddr (&t)[3]) {
         const float dx = p.rays_d_cam[r * 3 + 0], dy = p.rays_d_cam[r * 3 + 1], dz = p.rays_d_cam[r * 3 + 2];
-        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
         const float* M = p.cam2world + n * 16;
-        const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
-        const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
-        const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
-        const float zstep = (S > 1) ? (p.z_lin[1] - p.z_lin[0]) : 0.f;
-        const float* jit = p.jitter ? p.jitter + ray * S : nullptr;
-        const float* sgn = p.sigma_noise ? p.sigma_noise + ray * S : nullptr;
-        const float* tex_b = p.tex_planes + n * p.tex_stride[0];
-        const float* geo_b = p.geo_planes + n * p.geo_stride[0];
+        float px = __fmul_rn(dx, zl), py = __fmul_rn(dy, zl), pz = __fmul_rn(dz, zl);
+        if (p.jitter) {
+            const float off = __fmul_rn(__fsub_rn(jl, 0.5f), zstep);
+            px = __fadd_rn(px, __fmul_rn(off, dx));
+            py = __fadd_rn(py, __fmul_rn(off, dy));
+            pz = __fadd_rn(pz, __fmul_rn(off, dz));
+        }
+        const float wx = fmaf(M[0], px, fmaf(M[1], py, fmaf(M[2], pz, M[3])));
+        const float wy = fmaf(M[4], px, fmaf(M[5], py, fmaf(M[6], pz, M[7])));
+        const float wz = fmaf(M[8], px, fmaf(M[9], py, fmaf(M[10], pz, M[11])));
+        t[0] = make_tap_addr(wx, wy, p.W, p.H, sH, sW);
+        t[1] = make_tap_addr(wy, wz, p.W, p.H, sH, sW);
+        t[2] = make_tap_addr(wx, wz, p.W, p.H, sH, sW);
+    };
 
-        float acc_t[8], acc_g[8];
+    // Software pipeline over the tiles (ray, s0) of this wave, flattened across rays.  The loads of a tile's texture taps fly during
+    // its geometry MLP and the geometry taps of the NEXT tile during its texture MLP: with the L1 access rate out of the way (gather
+    // layout) the kernel is otherwise the sum of its exposed gather round trips and its arithmetic (2 waves per SIMD hide little).
+    // vmcnt retires in order, so nothing that is needed during an MLP may be loaded after the taps that fly across it: the small
+    // loads of a tile (its depths, the next tile's depths) are issued first, and the kernel must not spill (a scratch reload inside
+    // an MLP would wait for the taps).
+    // (ray, image n, ray-in-image r, s0) of the current tile: wave-uniform, kept in scalar registers (the image index advances by
+    // comparison, not by a 64-bit division per tile; plane bases are scalar pointers for the scalar-base loads)
+    int64_t ray = ray_begin + wid;
+    int n = __builtin_amdgcn_readfirstlane((int)(ray / p.rays_per_img));
+    int r = __builtin_amdgcn_readfirstlane((int)(ray - (int64_t)n * p.rays_per_img));
+    int s0 = 0;
+    bool have = ray < ray_end;
+    TapAddr t[3];
+    TapBuf<C> buf;
+    if (have) {
+        float zl, jl;
+        tile_depth(ray, 0, zl, jl);
+        tile_taps(n, r, zl, jl, t);
+        issue_taps<C>(uniform_ptr(p.geo_planes + n * p.geo_stride[0]), t, gl, buf);
+    }
+    float acc_t[8], acc_g[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc_t[i] = 0.f; acc_g[i] = 0.f; }
-        float carry = 1.0f, wsum = 0.f, dsum = 0.f;
+    for (int i = 0; i < 8; ++i) { acc_t[i] = 0.f; acc_g[i] = 0.f; }
+    float carry = 1.0f, wsum = 0.f, dsum = 0.f;
 
-        for (int s0 = 0; s0 < S; s0 += 16) {
-            // --- gather layout: position of sample s0 + lane / 4 (camera space -> jitter -> world) and its taps ---
-            TapAddr t[3];
-            {
-                const int sl = min(s0 + gather_sample(lane), S - 1);
-                const float zl = p.z_lin[sl];
-                float px = __fmul_rn(dx, zl), py = __fmul_rn(dy, zl), pz = __fmul_rn(dz, zl);
-                if (jit) {
-                    const float off = __fmul_rn(__fsub_rn(jit[sl], 0.5f), zstep);
-                    px = __fadd_rn(px, __fmul_rn(off, dx));
-                    py = __fadd_rn(py, __fmul_rn(off, dy));
-                    pz = __fadd_rn(pz, __fmul_rn(off, dz));
-                }
-                const float wx = fmaf(m00, px, fmaf(m01, py, fmaf(m02, pz, m03)));
-                const float wy = fmaf(m10, px, fmaf(m11, py, fmaf(m12, pz, m13)));
-                const float wz = fmaf(m20, px, fmaf(m21, py, fmaf(m22, pz, m23)));
-                t[0] = make_tap_addr(wx, wy, p.W, p.H, sH, sW);
-                t[1] = make_tap_addr(wy, wz, p.W, p.H, sH, sW);
-                t[2] = make_tap_addr(wx, wz, p.W, p.H, sH, sW);
-            }
-            // --- matrix layout: depth of sample s0 + lane % 16 for the compositing ---
-            const int s = s0 + j;
-            const bool live = s < S;
-            const int sc = live ? s : S - 1;
-            float z = p.z_lin[sc];
-            float znext = (sc + 1 < S) ? p.z_lin[sc + 1] : 0.f;
-            if (jit) {
-                z = __fadd_rn(z, __fmul_rn(__fsub_rn(jit[sc], 0.5f), zstep));
-                if (sc + 1 < S) znext = __fadd_rn(znext, __fmul_rn(__fsub_rn(jit[sc + 1], 0.5f), zstep));
-            }
-            const int gl = gather_block(lane);
-            float fg[K::NF], ft[K::NF];
-            f32x4 og[2], ot[2];
-            gather_features<C>(geo_b, t, gl, fg);
-            to_matrix_lanes(fg);
-            mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
-            asm volatile("" ::: "memory");     // keep the second gather behind the first MLP (register budget)
-            gather_features<C>(tex_b, t, gl, ft);
-            to_matrix_lanes(ft);
-            mlp_branch<C, HID, SPLIT>(s_tex, ft, ot);
-            // --- compositing weights ---
-            float sigma = __shfl(og[0][0], j);                    // feature 0 lives in lanes g = 0
-            if (sgn) sigma += sgn[sc];
-            const float dens = p.clamp_mode == 0 ? softplus_fast(sigma) : fmaxf(sigma, 0.f);
-            const float delta = (sc + 1 < S) ? (znext - z) * dnorm : 1e10f;
-            const float alpha = live ? 1.0f - __expf(-delta * dens) : 0.f;
-            const float fac = live ? (1.0f - alpha + 1e-10f) : 1.0f;
-            float tot;
-            const float excl = seg16_excl_prod(fac, tot);
-            const float w = alpha * (carry * excl);
-            carry *= tot;
-            wsum += w; dsum += w * z;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    acc_g[mt * 4 + rr] += w * og[mt][rr];
-                    acc_t[mt * 4 + rr] += w * ot[mt][rr];
-                }
+    while (have) {
+        // successor tile
+        int s0n = s0 + 16, nn = n, rn = r;
+        int64_t rayn = ray;
+        if (s0n >= S) {
+            s0n = 0; rayn = ray + 4; rn = r + 4;
+            while (rn >= p.rays_per_img) { rn -= (int)p.rays_per_img; ++nn; }
         }
-        // --- close the ray: reduce over the 16 samples held by lanes with equal g ---
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            wsum += __shfl_xor(wsum, off); dsum += __shfl_xor(dsum, off);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { acc_g[i] += __shfl_xor(acc_g[i], off); acc_t[i] += __shfl_xor(acc_t[i], off); }
+        const bool haven = rayn < ray_end;
+        // the prefetches below are unconditional (a conditional definition of the loop-carried tap buffer costs a register copy per
+        // value and iteration): past the last tile they re-read this one
+        const int64_t rayp = haven ? rayn : ray;
+        const int np = haven ? nn : n, rp = haven ? rn : r, s0p = haven ? s0n : s0;
+        // --- matrix layout: depth of sample s0 + lane % 16 for the compositing; gather layout: depths of the next tile ---
+        const int s = s0 + j;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        float z = p.z_lin[sc];
+        float znext = (sc + 1 < S) ? p.z_lin[sc + 1] : 0.f;
+        if (p.jitter) {
+            const float* jit = p.jitter + ray * S;
+            z = __fadd_rn(z, __fmul_rn(__fsub_rn(jit[sc], 0.5f), zstep));
+            if (sc + 1 < S) znext = __fadd_rn(znext, __fmul_rn(__fsub_rn(jit[sc + 1], 0.5f), zstep));
         }
-        if (j == 0) {
-            // last_back needs the un-weighted features of the final sample; not supported in the fused
-            // kernel (host guards), white_back / max_depth are.
-            const float bg = p.white_back ? (1.0f - wsum) : 0.f;
-            float* of = p.out_feat + (int64_t)n * nch * p.rays_per_img + r;
+        const float noise = p.sigma_noise ? p.sigma_noise[ray * S + sc] : 0.f;
+        float zln, jln;
+        tile_depth(rayp, s0p, zln, jln);
+
+        float fg[K::NF], ft[K::NF];
+        f32x4 og[2], ot[2];
+        blend_taps<C>(buf, t, fg);
+        to_matrix_lanes(fg);
+        issue_taps<C>(uniform_ptr(p.tex_planes + n * p.tex_stride[0]), t, gl, buf);          // in flight during the geometry MLP
+        mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
+
+        // --- compositing weights (before the texture MLP: the geometry outputs die here) ---
+        float sigma = __shfl(og[0][0], j);                    // feature 0 lives in lanes g = 0
+        sigma += noise;
+        const float dens = p.clamp_mode == 0 ? softplus_fast(sigma) : fmaxf(sigma, 0.f);
+        float dnorm;
+        {
+            const float dx = p.rays_d_cam[r * 3 + 0], dy = p.rays_d_cam[r * 3 + 1], dz = p.rays_d_cam[r * 3 + 2];
+            dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+        const float delta = (sc + 1 < S) ? (znext - z) * dnorm : 1e10f;
+        const float alpha = live ? 1.0f - __expf(-delta * dens) : 0.f;
+        const float fac = live ? (1.0f - alpha + 1e-10f) : 1.0f;
+        float tot;
+        const float excl = seg16_excl_prod(fac, tot);
+        const float w = alpha * (carry * excl);
+        carry *= tot;
+        wsum += w; dsum += w * z;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int idx = 16 * mt + 4 * g + rr;
-                    if (idx < p.feat_ch) of[(int64_t)idx * p.rays_per_img] = acc_t[mt * 4 + rr] + bg;
-                    if (idx >= 1 && idx <= p.seg_ch) of[(int64_t)(p.feat_ch + idx - 1) * p.rays_per_img] = acc_g[mt * 4 + rr] + bg;
-                }
-            if (g == 0) {
-                if (p.out_depth) p.out_depth[ray] = dsum + ((p.max_depth != 0.f) ? (1.0f - wsum) * p.max_depth : 0.f);
-                if (p.out_wsum) p.out_wsum[ray] = wsum;
+            for (int rr = 0; rr < 4; ++rr) acc_g[mt * 4 + rr] += w * og[mt][rr];
+
+        blend_taps<C>(buf, t, ft);
+        to_matrix_lanes(ft);
+        tile_taps(np, rp, zln, jln, t);                                         // next tile's geometry taps: during the texture MLP
+        issue_taps<C>(uniform_ptr(p.geo_planes + np * p.geo_stride[0]), t, gl, buf);
+        mlp_branch<C, HID, SPLIT>(s_tex, ft, ot);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) acc_t[mt * 4 + rr] += w * ot[mt][rr];
+
+        if (s0n == 0) {
+            // --- close the ray: reduce over the 16 samples held by lanes with equal g ---
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                wsum += __shfl_xor(wsum, off); dsum += __shfl_xor(dsum, off);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { acc_g[i] += __shfl_xor(acc_g[i], off); acc_t[i] += __shfl_xor(acc_t[i], off); }
             }
+            if (j == 0) {
+                // last_back needs the un-weighted features of the final sample; not supported in the fused
+                // kernel (host guards), white_back / max_depth are.
+                const float bg = p.white_back ? (1.0f - wsum) : 0.f;
+                float* of = p.out_feat + (int64_t)n * nch * p.rays_per_img + r;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int idx = 16 * mt + 4 * g + rr;
+                        if (idx < p.feat_ch) of[(int64_t)idx * p.rays_per_img] = acc_t[mt * 4 + rr] + bg;
+                        if (idx >= 1 && idx <= p.seg_ch) of[(int64_t)(p.feat_ch + idx - 1) * p.rays_per_img] = acc_g[mt * 4 + rr] + bg;
+                    }
+                if (g == 0) {
+                    if (p.out_depth) p.out_depth[ray] = dsum + ((p.max_depth != 0.f) ? (1.0f - wsum) * p.max_depth : 0.f);
+                    if (p.out_wsum) p.out_wsum[ray] = wsum;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc_t[i] = 0.f; acc_g[i] = 0.f; }
+            carry = 1.0f; wsum = 0.f; dsum = 0.f;
         }
+        ray = rayn; n = nn; r = rn; s0 = s0n; have = haven;
     }
 }
 
 // Where sample_voxel takes its points from: an [n, m, 3] array, or the extract_shapes.py lattice generated in registers.
 struct PointsFromMemory {
     const float* pts;
-    __device__ __forceinline__ void get(int64_t row, int64_t /*m*/, float& x, float& y, float& z) const {
+    // `row`: global row (image * m + idx); `idx`: the row inside its image
+    __device__ __forceinline__ void get(int64_t row, int64_t /*idx*/, float& x, float& y, float& z) const {
         x = pts[row * 3 + 0]; y = pts[row * 3 + 1]; z = pts[row * 3 + 2];
     }
 };
@@ -539,11 +626,12 @@ struct PointsFromMemory {
 struct PointsFromLattice {
     ide3d_lattice lat;
     int64_t first;
-    __device__ __forceinline__ void get(int64_t row, int64_t m, float& x, float& y, float& z) const {
-        const int64_t i = first + row % m;
+    __device__ __forceinline__ void get(int64_t /*row*/, int64_t idx, float& x, float& y, float& z) const {
+        const int64_t i = first + idx;
         const float fn = (float)lat.n, fi = (float)i;                       // int64 -> fp32, round to nearest even
         const float q = __fdiv_rn(fi, fn);
-        const float s2 = (float)(i % lat.n), s1 = fmodf(q, fn), s0 = fmodf(__fdiv_rn(q, fn), fn);
+        const int64_t r2 = (i >> 32) == 0 ? (int64_t)((unsigned)i % (unsigned)lat.n) : i % lat.n;    // 32-bit remainder when it fits
+        const float s2 = (float)r2, s1 = fmodf(q, fn), s0 = fmodf(__fdiv_rn(q, fn), fn);
         x = __fmul_rn(__fadd_rn(__fmul_rn(s0, lat.voxel_size), lat.corner[2]), lat.scale);
         y = __fmul_rn(__fadd_rn(__fmul_rn(s1, lat.voxel_size), lat.corner[1]), lat.scale);
         z = __fmul_rn(__fadd_rn(__fmul_rn(s2, lat.voxel_size), lat.corner[0]), lat.scale);
@@ -554,17 +642,14 @@ template <class Src>
 __global__ void lattice_points_kernel(Src src, int64_t count, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float x, y, z;
-        src.get(i, count, x, y, z);
+        src.get(i, i, x, y, z);
         out[i * 3 + 0] = x; out[i * 3 + 1] = y; out[i * 3 + 2] = z;
     }
 }
 
 // sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
-#ifndef IDE3D_VOX_LB
-#define IDE3D_VOX_LB 2
-#endif
 template <int C, int HID, class Src, bool SPLIT>
-__global__ void __launch_bounds__(256, IDE3D_VOX_LB)
+__global__ void __launch_bounds__(256, 2)
 sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
                     float* __restrict__ out, float* __restrict__ out_sigma, int sigma_only, int64_t tiles_per_block) {
     using K = RmCfg<C, HID>;
@@ -580,8 +665,8 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
         for (int i = threadIdx.x; i <= HID; i += blockDim.x) s_row[i] = (i < HID) ? p.geo_w1[i] : p.geo_b1[0];
     }
     __syncthreads();
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
-    const int g = lane >> 4, j = lane & 15;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15, gl = gather_block(lane);
     const int width = p.feat_ch + p.seg_ch + 1;
     const int sH = (int)p.tex_stride[2], sW = (int)p.tex_stride[3];
     float* stage = s_stage + wid * 16 * width;
@@ -591,34 +676,77 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     const int64_t tile_begin = (int64_t)blk * tiles_per_block;
     int64_t tile_end = tile_begin + tiles_per_block;
     if (tile_end > ntiles) tile_end = ntiles;
-    for (int64_t tile = tile_begin + wid; tile < tile_end; tile += 4) {
+
+    // Software pipeline over this wave's tiles (same scheme as render_rays_kernel): the texture taps of a tile fly during its geometry
+    // MLP, the geometry taps of the next tile during its texture MLP (sigma only: during its only MLP).  Wave-uniform per tile: the
+    // image n0 of its first row (scalar plane bases); a lane whose row lies `dn` images further on (a tile straddling images: m not a
+    // multiple of 16) adds dn image strides to its byte offsets.
+    int64_t tile = tile_begin + wid;
+    int n0 = 0;
+    int64_t img_end = m;                                   // first row of image n0 + 1
+    auto advance_image = [&](int64_t row0) { while (row0 >= img_end && n0 + 1 < p.n) { ++n0; img_end += m; } };
+    // the point of row row0 + lane / 4 (gather layout) and how many images past n0 it lies
+    auto tile_point = [&](int64_t row0, float& wx, float& wy, float& wz, int& dn) {
+        const int64_t rl = row0 + gather_sample(lane);
+        const int64_t rc = rl < rows ? rl : rows - 1;
+        dn = 0;
+        int64_t e = img_end;
+        while (rc >= e) { ++dn; e += m; }
+        src.get(rc, rc - (e - m), wx, wy, wz);
+    };
+    auto tile_taps = [&](float wx, float wy, float wz, TapAddr (&t)[3]) {
+        t[0] = make_tap_addr(wx, wy, p.W, p.H, sH, sW);
+        t[1] = make_tap_addr(wy, wz, p.W, p.H, sH, sW);
+        t[2] = make_tap_addr(wx, wz, p.W, p.H, sH, sW);
+    };
+    const unsigned geo_img_b = (unsigned)p.geo_stride[0] * 4u, tex_img_b = (unsigned)p.tex_stride[0] * 4u;
+
+    bool have = tile < tile_end;
+    TapAddr t[3];
+    TapBuf<C> buf;
+    int dn = 0;
+    if (have) {
+        float wx, wy, wz;
+        advance_image(tile * 16);
+        tile_point(tile * 16, wx, wy, wz, dn);
+        tile_taps(wx, wy, wz, t);
+        issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
+    }
+    while (have) {
         const int64_t row0 = tile * 16;
         const int64_t row = row0 + j;
         const bool live = row < rows;
-        // gather layout (lane 4 j + g): the point and the taps of row row0 + lane / 4
-        const int64_t rl = row0 + gather_sample(lane);
-        const int64_t rc = rl < rows ? rl : rows - 1;
-        const int n = (int)(rc / m);
-        const int gl = gather_block(lane);
-        float wx, wy, wz;
-        src.get(rc, m, wx, wy, wz);
-        const TapAddr t[3] = { make_tap_addr(wx, wy, p.W, p.H, sH, sW), make_tap_addr(wy, wz, p.W, p.H, sH, sW),
-                               make_tap_addr(wx, wz, p.W, p.H, sH, sW) };
+        const int64_t tilen = tile + 4;
+        const bool haven = tilen < tile_end;
+        const int n0c = n0, dnc = dn;
+        // next tile's points first (PointsFromMemory: three small loads, ahead of the taps that fly across the MLPs).  The prefetch is
+        // unconditional (a conditional definition of the loop-carried tap buffer costs a register copy per value and iteration): past
+        // the last tile it re-reads this one.
+        const int64_t tilep = haven ? tilen : tile;
+        float wxn, wyn, wzn;
+        advance_image(tilep * 16);
+        tile_point(tilep * 16, wxn, wyn, wzn, dn);
         float fg[K::NF];
-        gather_features<C>(p.geo_planes + n * p.geo_stride[0], t, gl, fg);
+        blend_taps<C>(buf, t, fg);
         to_matrix_lanes(fg);
         if (sigma_only) {
+            tile_taps(wxn, wyn, wzn, t);
+            issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
             float sig;
             if constexpr (SPLIT) sig = mlp_sigma_split<C, HID>(s_geo, s_row, fg);
             else sig = mlp_sigma<C, HID>(reinterpret_cast<const float*>(s_geo), s_row, fg);
             if (g == 0 && live) out_sigma[row] = sig;
+            tile = tilen; have = haven;
             continue;
         }
+        issue_taps<C>(uniform_ptr(p.tex_planes + n0c * p.tex_stride[0]), t, gl, buf, (unsigned)dnc * tex_img_b);
         f32x4 og[2];
         mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
         float ft[K::NF];
-        gather_features<C>(p.tex_planes + n * p.tex_stride[0], t, gl, ft);
+        blend_taps<C>(buf, t, ft);
         to_matrix_lanes(ft);
+        tile_taps(wxn, wyn, wzn, t);
+        issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
         f32x4 ot[2];
         mlp_branch<C, HID, SPLIT>(s_tex, ft, ot);
         // stage the 16 x width row block, then write it out contiguously
@@ -638,6 +766,7 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
         float* dst = out + row0 * width;
         for (int i = lane; i < nel; i += kWave) dst[i] = stage[i];
         __builtin_amdgcn_wave_barrier();
+        tile = tilen; have = haven;
     }
 }
 
@@ -695,7 +824,8 @@ static bool planes_fast(const ide3d_render_params& p) {
     };
     return ok(p.tex_planes, p.tex_stride) && ok(p.geo_planes, p.geo_stride) &&
            p.tex_stride[2] == p.geo_stride[2] && p.tex_stride[3] == p.geo_stride[3] &&
-           p.tex_stride[2] * p.H < 0x7fffffffLL && p.tex_stride[3] * p.W < 0x7fffffffLL;
+           (p.tex_stride[2] * p.H + p.tex_stride[3] * p.W + 3 * p.C) * 4 < 0x7fffffffLL &&     // byte offsets inside an image: 31 bits
+           p.tex_stride[0] * 64 < 0x7fffffffLL && p.geo_stride[0] * 64 < 0x7fffffffLL;           // + up to 15 image strides (straddling tiles)
 }
 
 }  // namespace ide3d

@@ -225,6 +225,32 @@ def test_extract_shapes_density_cube(golden, gpu_device):
     _rel(torch.from_numpy(got).reshape(-1), ref, 5e-4, 'driver density cube')
 
 
+@pytest.mark.parametrize('n,m', [(3, 37), (4, 5), (2, 16), (5, 1), (2, 1000)])
+def test_sample_voxel_tiles_that_straddle_images(gpu_device, n, m):
+    """sample_voxel works on tiles of 16 rows of the flattened [n * m] point list and the tiles are software-pipelined: when m is
+    not a multiple of 16 a tile spans two (m < 16: several) images and its lanes read different tri-planes.  A batched call must equal,
+    bit for bit, the per-image calls (one image per call never straddles), for the full rows, the densities and the lattice."""
+    from training import triplane
+    torch.manual_seed(n * 100 + m)
+    R = triplane.TriplaneRenderer(triplane.GeneratorSpec()).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(m)
+    tex = (torch.randn(n, 96, 64, 64, generator=g) * 0.7).to(gpu_device).contiguous(memory_format=torch.channels_last)
+    geo = (torch.randn(n, 96, 64, 64, generator=g) * 0.7).to(gpu_device).contiguous(memory_format=torch.channels_last)
+    pts = (torch.rand(n, m, 3, generator=g) * 2.2 - 1.1).to(gpu_device)             # some points outside the planes (zero padding)
+    before = _calls('sample_voxel')
+    with torch.no_grad():
+        full = R.sample_voxel(tex, geo, pts)
+        sig = R.sample_voxel(tex, geo, pts, sigma_only=True)
+        one = torch.cat([R.sample_voxel(tex[i:i + 1], geo[i:i + 1], pts[i:i + 1]) for i in range(n)])
+        lat = R.density_lattice(tex, geo, 16, 2.0 / 15, np.array([-1.0, -1.0, -1.0]), 0.9, 3, m)
+        lat1 = torch.cat([R.density_lattice(tex[i:i + 1], geo[i:i + 1], 16, 2.0 / 15, np.array([-1.0, -1.0, -1.0]), 0.9, 3, m) for i in range(n)])
+    assert _calls('sample_voxel') - before == 2 + n
+    assert full.shape == (n * m, 52) and sig.shape == (n * m,)
+    assert torch.equal(full, one), 'batched rows differ from per-image rows'
+    assert_close(sig, one[:, -1], rtol=1e-4, atol=1e-5)          # the sigma-only branch sums row 0 of the second layer on the VALU
+    assert torch.equal(lat, lat1), 'batched lattice densities differ from per-image ones'
+
+
 def test_video_sweep_gpu_vs_cpu(golden):
     """gen_videos.py 2x2 grid sweep (training.video_render) on the GPU == the same driver on the CPU definitions."""
     from training import video_render
