@@ -650,8 +650,7 @@ __global__ void lattice_points_kernel(Src src, int64_t count, float* __restrict_
 // sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
 template <int C, int HID, class Src, bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
-sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
-                    float* __restrict__ out, float* __restrict__ out_sigma, int sigma_only, int64_t tiles_per_block) {
+sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restrict__ out, int64_t tiles_per_block) {
     using K = RmCfg<C, HID>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MB = MlpBytes<C, HID, SPLIT>::value;
@@ -659,11 +658,7 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     unsigned char* s_tex = s_geo + MB;
     float* s_stage = reinterpret_cast<float*>(s_geo + 2 * MB);                 // [4 waves][16 samples][width] row staging
     stage_branch<C, HID, SPLIT>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
-    if (!sigma_only) stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
-    float* const s_row = reinterpret_cast<float*>(s_tex);                        // sigma-only: row 0 of geo_w1 + its bias live where the texture MLP would
-    if (sigma_only) {
-        for (int i = threadIdx.x; i <= HID; i += blockDim.x) s_row[i] = (i < HID) ? p.geo_w1[i] : p.geo_b1[0];
-    }
+    stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
     __syncthreads();
     const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15, gl = gather_block(lane);
@@ -678,7 +673,7 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     if (tile_end > ntiles) tile_end = ntiles;
 
     // Software pipeline over this wave's tiles (same scheme as render_rays_kernel): the texture taps of a tile fly during its geometry
-    // MLP, the geometry taps of the next tile during its texture MLP (sigma only: during its only MLP).  Wave-uniform per tile: the
+    // MLP, the geometry taps of the next tile during its texture MLP.  Wave-uniform per tile: the
     // image n0 of its first row (scalar plane bases); a lane whose row lies `dn` images further on (a tile straddling images: m not a
     // multiple of 16) adds dn image strides to its byte offsets.
     int64_t tile = tile_begin + wid;
@@ -714,8 +709,6 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     }
     while (have) {
         const int64_t row0 = tile * 16;
-        const int64_t row = row0 + j;
-        const bool live = row < rows;
         const int64_t tilen = tile + 4;
         const bool haven = tilen < tile_end;
         const int n0c = n0, dnc = dn;
@@ -729,16 +722,6 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
         float fg[K::NF];
         blend_taps<C>(buf, t, fg);
         to_matrix_lanes(fg);
-        if (sigma_only) {
-            tile_taps(wxn, wyn, wzn, t);
-            issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
-            float sig;
-            if constexpr (SPLIT) sig = mlp_sigma_split<C, HID>(s_geo, s_row, fg);
-            else sig = mlp_sigma<C, HID>(reinterpret_cast<const float*>(s_geo), s_row, fg);
-            if (g == 0 && live) out_sigma[row] = sig;
-            tile = tilen; have = haven;
-            continue;
-        }
         issue_taps<C>(uniform_ptr(p.tex_planes + n0c * p.tex_stride[0]), t, gl, buf, (unsigned)dnc * tex_img_b);
         f32x4 og[2];
         mlp_branch<C, HID, SPLIT>(s_geo, fg, og);
@@ -770,6 +753,93 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m,
     }
 }
 
+// Densities only (extract_shapes.py's cube, sample_voxel(sigma_only)): one gather, the hidden layer, row 0 of the second layer.  The
+// kernel is bound by its vector instructions (90 % VALU-busy before this form), a third of them the point and the tap addresses of
+// the tile — which every lane of a quad computes alike.  So the points and taps are computed for 64 rows at once, lane = row (the
+// `super tile`), and each of its four 16-row tiles fetches its own from the lanes that hold them (ds_bpermute: 25 values per tile
+// instead of ~300 vector instructions).  Same software pipeline as above: the taps of the next tile fly during the MLP of this one.
+template <int C, int HID, class Src, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+density_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restrict__ out_sigma, int64_t supers_per_block) {
+    using K = RmCfg<C, HID>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
+    float* const s_row = reinterpret_cast<float*>(s_geo + MlpBytes<C, HID, SPLIT>::value);     // row 0 of geo_w1 + its bias
+    stage_branch<C, HID, SPLIT>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
+    for (int i = threadIdx.x; i <= HID; i += blockDim.x) s_row[i] = (i < HID) ? p.geo_w1[i] : p.geo_b1[0];
+    __syncthreads();
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15, gl = gather_block(lane);
+    const int sH = (int)p.geo_stride[2], sW = (int)p.geo_stride[3];
+    const int64_t rows = (int64_t)p.n * m;
+    const int64_t nsuper = cdiv64(rows, 64);
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t super_begin = (int64_t)blk * supers_per_block;
+    int64_t super_end = super_begin + supers_per_block;
+    if (super_end > nsuper) super_end = nsuper;
+    const unsigned geo_img_b = (unsigned)p.geo_stride[0] * 4u;
+
+    int n0 = 0;                                            // image of the first row of the super tile whose taps `tl` holds
+    int64_t img_end = m;
+    // taps of row 64 st + lane, and how many images past n0 that row lies (a super tile that straddles images)
+    auto super_taps = [&](int64_t st, TapAddr (&tl)[3], int& dnl) {
+        const int64_t row0 = st * 64;
+        while (row0 >= img_end && n0 + 1 < p.n) { ++n0; img_end += m; }
+        const int64_t rl = row0 + lane;
+        const int64_t rc = rl < rows ? rl : rows - 1;
+        dnl = 0;
+        int64_t e = img_end;
+        while (rc >= e) { ++dnl; e += m; }
+        float wx, wy, wz;
+        src.get(rc, rc - (e - m), wx, wy, wz);
+        tl[0] = make_tap_addr(wx, wy, p.W, p.H, sH, sW);
+        tl[1] = make_tap_addr(wy, wz, p.W, p.H, sH, sW);
+        tl[2] = make_tap_addr(wx, wz, p.W, p.H, sH, sW);
+    };
+    // tile k of the super tile, gather layout: lane 4 j + g takes the taps of row 16 k + j from lane 16 k + j
+    auto tile_taps = [&](const TapAddr (&tl)[3], int dnl, int k, TapAddr (&t)[3], int& dn) {
+        const int src_b = (16 * k + gather_sample(lane)) << 2;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            t[pl].o00 = __builtin_amdgcn_ds_bpermute(src_b, tl[pl].o00); t[pl].o01 = __builtin_amdgcn_ds_bpermute(src_b, tl[pl].o01);
+            t[pl].o10 = __builtin_amdgcn_ds_bpermute(src_b, tl[pl].o10); t[pl].o11 = __builtin_amdgcn_ds_bpermute(src_b, tl[pl].o11);
+            t[pl].w00 = __int_as_float(__builtin_amdgcn_ds_bpermute(src_b, __float_as_int(tl[pl].w00)));
+            t[pl].w01 = __int_as_float(__builtin_amdgcn_ds_bpermute(src_b, __float_as_int(tl[pl].w01)));
+            t[pl].w10 = __int_as_float(__builtin_amdgcn_ds_bpermute(src_b, __float_as_int(tl[pl].w10)));
+            t[pl].w11 = __int_as_float(__builtin_amdgcn_ds_bpermute(src_b, __float_as_int(tl[pl].w11)));
+        }
+        dn = __builtin_amdgcn_ds_bpermute(src_b, dnl);
+    };
+
+    int64_t st = super_begin + wid;
+    if (st >= super_end) return;
+    TapAddr tl[3], t[3];
+    TapBuf<C> buf;
+    int dnl, dn;
+    super_taps(st, tl, dnl);
+    tile_taps(tl, dnl, 0, t, dn);
+    issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
+    while (st < super_end) {
+        const int64_t stn = st + 4;
+        const int64_t stp = stn < super_end ? stn : st;              // the prefetch past the last super tile re-reads this one
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t row = st * 64 + 16 * k + j;
+            float fg[K::NF];
+            blend_taps<C>(buf, t, fg);
+            to_matrix_lanes(fg);
+            if (k == 3) super_taps(stp, tl, dnl);
+            tile_taps(tl, dnl, (k + 1) & 3, t, dn);
+            issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
+            float sig;
+            if constexpr (SPLIT) sig = mlp_sigma_split<C, HID>(s_geo, s_row, fg);
+            else sig = mlp_sigma<C, HID>(reinterpret_cast<const float*>(s_geo), s_row, fg);
+            if (g == 0 && row < rows) out_sigma[row] = sig;
+        }
+        st = stn;
+    }
+}
+
 template <int C, int HID, bool SPLIT = false>
 static int launch_render(const ide3d_render_params& p, hipStream_t st) {
     const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value;
@@ -788,6 +858,19 @@ static int launch_render(const ide3d_render_params& p, hipStream_t st) {
 template <int C, int HID, class Src, bool SPLIT = false>
 static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m, float* out, float* out_sigma,
                         int sigma_only, hipStream_t st) {
+    if (sigma_only) {
+        const size_t lds_bytes = (size_t)MlpBytes<C, HID, SPLIT>::value + (size_t)(HID + 4) * sizeof(float);
+        const int64_t nsuper = cdiv64((int64_t)p.n * m, 64);
+        int64_t nblk = kNumCU * 2;
+        int64_t spb = cdiv64(cdiv64(nsuper, nblk), 4) * 4;
+        if (spb < 4) spb = 4;
+        nblk = cdiv64(nsuper, spb);
+        auto kern = density_kernel<C, HID, Src, SPLIT>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out_sigma, spb);
+        IDE3D_CHECK_LAUNCH("sample_voxel (densities)");
+        return IDE3D_OK;
+    }
     const int width = p.feat_ch + p.seg_ch + 1;
     const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value + (size_t)4 * 16 * width * sizeof(float);
     const int64_t ntiles = cdiv64((int64_t)p.n * m, 16);
@@ -797,7 +880,7 @@ static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m,
     nblk = cdiv64(ntiles, tpb);
     auto kern = sample_voxel_kernel<C, HID, Src, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out, out_sigma, sigma_only, tpb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out, tpb);
     IDE3D_CHECK_LAUNCH("sample_voxel");
     return IDE3D_OK;
 }
