@@ -169,9 +169,9 @@ def cases(device):
                 lambda: R.sample_voxel(tex, geo, coords)))
     vs = 2.0 / 255
     corner = np.array([-1.0, -1.0, -1.0])
-    out.append(('density_lattice 256^3 (1 image, sigma only), geometry-branch MLP flops', 'sample_voxel', 'mfma',
+    out.append(('density_lattice 256^3 (1 image, sigma only), geometry-branch MLP flops', 'density_kernel', 'mfma',
                 256 ** 3 * 2 * (32 * 64 + 64 * 1), lambda: R.density_lattice(tex[:1], geo[:1], 256, vs, corner, 0.9, 0, 256 ** 3)))
-    out.append(('density_lattice 256^3, HBM bytes (planes + sigma out)', 'sample_voxel', 'hbm',
+    out.append(('density_lattice 256^3, HBM bytes (planes + sigma out)', 'density_kernel', 'hbm',
                 (3 * C * H * H + 256 ** 3) * 4, lambda: R.density_lattice(tex[:1], geo[:1], 256, vs, corner, 0.9, 0, 256 ** 3)))
 
     # ---- a14 compositing, a15 sample_pdf ---------------------------------------------------------------------------------
