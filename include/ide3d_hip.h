@@ -394,7 +394,10 @@ int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
  *      same SIMD beside an LDS-fed bf16 / fp16 MFMA loop was measured to return wrong results on MI355X (DESIGN.md section 4.2;
  *      this library contains no such instructions), so a caller selects them only where no foreign kernel shares the GPU with the
  *      convolutions — the render path does (`GeneratorSpec.conv_arithmetic`, `bench.py --conv-arith`).
- * The same switch selects the arithmetic of per-image 1x1 heads with <= 32 or 161..192 outputs on grids of >= 512 workgroups.
+ * The same switch selects the arithmetic of per-image 1x1 heads with <= 32 or 161..192 outputs on grids of >= 512 workgroups, and of the
+ * two decoder MLPs inside ide3d_render_rays / ide3d_sample_voxel / ide3d_density_lattice at C = 32, hidden = 64: exact fp32 products
+ * on v_mfma_f32_16x16x4_f32 with fp32 (1) selected, bf16x6 (fp32-grade, 3 bf16 pieces per operand on v_mfma_f32_16x16x32_bf16)
+ * with any of the split arithmetics (3, 6, 16).
  * Packed weights in a modconv workspace are specific to the arithmetic they were packed for.
  */
 int     ide3d_set_conv_arithmetic(int32_t arith);
