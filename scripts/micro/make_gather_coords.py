@@ -10,9 +10,11 @@ g = torch.Generator().manual_seed(0)
 n = 4
 torch.randn(n, 96, 256, 256, generator=g)          # bench_gather draws the planes first: keep the jitter stream identical
 pts, z, d = vr.get_initial_rays_trig(n, 96, 'cpu', 18.0, (64, 64), 2.25, 3.3)
-cam = torch.cat([triplane.camera_label(y) for y in (-0.5, -0.15, 0.2, 0.5)])[:, :16].reshape(-1, 4, 4)
+yaws = tuple(float(v) for v in os.environ.get('GATHER_YAWS', '-0.5,-0.15,0.2,0.5').split(','))          # bench_gather's cameras by default
+cam = torch.cat([triplane.camera_label(y) for y in yaws])[:, :16].reshape(-1, 4, 4)
 wp, *_ = vr.transform_sampled_points(pts, z, d, 'cpu', h_stddev=0, v_stddev=0, camera=cam, mode=None, jitter=torch.rand(z.shape, generator=g))
 out = os.path.join(ROOT, 'scripts', 'micro', 'bin')
 os.makedirs(out, exist_ok=True)
-wp.reshape(n, -1, 3).contiguous().numpy().tofile(os.path.join(out, 'gather_coords.bin'))
-print('wrote', os.path.join(out, 'gather_coords.bin'))
+name = os.environ.get('GATHER_COORDS_NAME', 'gather_coords.bin')
+wp.reshape(n, -1, 3).contiguous().numpy().tofile(os.path.join(out, name))
+print('wrote', os.path.join(out, name))
