@@ -858,6 +858,14 @@ static int launch_render(const ide3d_render_params& p, hipStream_t st) {
 template <int C, int HID, class Src, bool SPLIT = false>
 static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m, float* out, float* out_sigma,
                         int sigma_only, hipStream_t st) {
+    // a lane whose row lies in a later image than the first row of its (super) tile adds whole image strides to its 32-bit byte
+    // offsets: at most rows_per_tile - 1 images when m = 1
+    {
+        const int64_t rows_per_tile = sigma_only ? 64 : 16;
+        const int64_t max_dn = (p.n > 1) ? ((rows_per_tile - 1) / (m > 0 ? m : 1) + 1 < p.n - 1 ? (rows_per_tile - 1) / (m > 0 ? m : 1) + 1 : p.n - 1) : 0;
+        const int64_t img = p.geo_stride[0] > p.tex_stride[0] ? p.geo_stride[0] : p.tex_stride[0];
+        if ((max_dn * img + img) * 4 >= 0xffffffffLL) { set_error("sample_voxel: too few points per image for planes this large"); return IDE3D_ENOKERNEL; }
+    }
     if (sigma_only) {
         const size_t lds_bytes = (size_t)MlpBytes<C, HID, SPLIT>::value + (size_t)(HID + 4) * sizeof(float);
         const int64_t nsuper = cdiv64((int64_t)p.n * m, 64);
@@ -907,8 +915,7 @@ static bool planes_fast(const ide3d_render_params& p) {
     };
     return ok(p.tex_planes, p.tex_stride) && ok(p.geo_planes, p.geo_stride) &&
            p.tex_stride[2] == p.geo_stride[2] && p.tex_stride[3] == p.geo_stride[3] &&
-           (p.tex_stride[2] * p.H + p.tex_stride[3] * p.W + 3 * p.C) * 4 < 0x7fffffffLL &&     // byte offsets inside an image: 31 bits
-           p.tex_stride[0] * 64 < 0x7fffffffLL && p.geo_stride[0] * 64 < 0x7fffffffLL;           // + up to 15 image strides (straddling tiles)
+           (p.tex_stride[2] * p.H + p.tex_stride[3] * p.W + 3 * p.C) * 4 < 0x7fffffffLL;       // byte offsets inside an image: 31 bits (launch_voxel bounds the image strides a straddling tile adds)
 }
 
 }  // namespace ide3d
