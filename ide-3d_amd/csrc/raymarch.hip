@@ -1,5 +1,5 @@
 // raymarch.hip — fused volumetric renderer for gfx950: ray set-up -> cam2world -> two tri-plane
-// gathers -> decoder MLPs (fp32 MFMA) -> depth-ordered alpha compositing, in ONE launch.
+// gathers -> decoder MLPs (MFMA) -> depth-ordered alpha compositing, in ONE launch.
 //
 // Replaces steps 3-7 of G.synthesis:
 //   get_initial_rays_trig      training/volumetric_rendering.py:77-97   (points = d_cam * z)
@@ -9,27 +9,28 @@
 //   renderer.sample_voxel MLPs (source absent upstream; spec = DESIGN.md "decoder")
 //   fancy_integration          training/volumetric_rendering.py:34-74
 //
-// CDNA4 mapping
-//   * One wavefront owns one ray and walks it in tiles of 16 depth samples.  Lane l = (g = l>>4,
-//     j = l&15): sample j of the tile, channel group g.  The four lanes of a sample each fetch
-//     C/16 float4 chunks per bilinear tap from the channels_last planes (full 128-B line use at C=32).
-//   * The two MLPs run on v_mfma_f32_16x16x4_f32 (exact fp32) in the *transposed* form
-//     out^T[features x samples] = W[features x K] * act^T[K x samples]: the gathered features already
-//     sit in the MFMA B-operand layout (k = l>>4, n = l&15) and the D layout of layer 1
-//     (row = 4*(l>>4)+r, col = l&15) is again a valid B operand for layer 2 once K is enumerated as
-//     k(t, g) = 16*(t/4) + 4g + t%4 — so activations never leave registers between gather, layer 1,
-//     layer 2 and compositing.  Weights are re-ordered once per workgroup into LDS in A-operand order
-//     (one ds_read_b128 feeds 4 MFMAs).
-//   * Compositing: sigma is broadcast from the g = 0 lanes, alpha / transmittance are evaluated by a
-//     16-lane segmented shuffle scan with the running transmittance carried across tiles, each lane
-//     accumulates w * feature for the 16 output features it holds, a 4-step xor-shuffle reduction over
-//     the 16 samples closes the ray.  Nothing but the final [n, feat+seg, rays] image, depth and
-//     weight sum is written.
-//   * Persistent workgroups (3 per CU) take contiguous ray ranges; the range order is XCD-remapped so
-//     neighbouring rays (neighbouring plane lines) share one XCD L2.
-// Compulsory HBM traffic per image: 2 tri-planes + jitter/noise in + (feat+seg+2)*rays*4 out.  The
-// planes are cache resident (L2 4 MiB/XCD + 256 MiB MALL), so this kernel is bound by the L1/TA gather
-// rate and the fp32 MFMA rate, not by HBM — see DESIGN.md.
+// CDNA4 mapping (round 3: DESIGN.md section 5.2c)
+//   * One wavefront owns one ray and walks it in tiles of 16 depth samples, software-pipelined over the tiles of all its rays: a
+//     tile's texture taps are in flight during its geometry MLP, the next tile's geometry taps during its texture MLP.
+//   * Two lane layouts.  The gathers run with lane 4 j + g (sample j, 16-byte channel block g): the four lanes of a quad read 64
+//     contiguous bytes of one bilinear tap — one L1 access; every tap load is the scalar-base form (plane pointer in SGPRs, 32-bit
+//     byte offset, plane / slice in the immediate), all 24 of a tri-plane issued before the first is used.  The blended features
+//     change lanes once (ds_bpermute) into the matrix layout lane 16 g + j (g = K block, j = column / sample).
+//   * The two MLPs run in the *transposed* form out^T[features x samples] = W[features x K] * act^T[K x samples]: the features sit in
+//     the B-operand layout and the D layout of layer 1 (row = 4*(l>>4)+r, col = l&15) is again a valid B operand for layer 2 once K
+//     is enumerated accordingly — activations never leave registers between gather, layer 1, layer 2 and compositing.  Weights are
+//     re-ordered once per workgroup into LDS in A-operand order.  Arithmetic: exact fp32 products on v_mfma_f32_16x16x4_f32
+//     (library default), or bf16x6 (fp32-grade: 3 bf16 pieces per operand, 6 products) on v_mfma_f32_16x16x32_bf16 when a split
+//     arithmetic is selected (ide3d_set_conv_arithmetic).
+//   * Compositing: sigma is broadcast from the g = 0 lanes, alpha / transmittance are evaluated by a 16-lane segmented shuffle scan
+//     with the running transmittance carried across tiles, each lane accumulates w * feature for the 16 output features it holds
+//     (the geometry outputs right after their MLP: they die before the texture MLP), a 4-step xor-shuffle reduction over the 16
+//     samples closes the ray.  Nothing but the final [n, feat+seg, rays] image, depth and weight sum is written.
+//   * Persistent workgroups (2 per CU) take contiguous ray ranges; the range order is XCD-remapped so neighbouring rays
+//     (neighbouring plane lines) share one XCD L2.
+// Compulsory HBM traffic per image: 2 tri-planes + jitter/noise in + (feat+seg+2)*rays*4 out.  The planes are cache resident
+// (L2 4 MiB/XCD + 256 MiB MALL); the kernel is bound by its vector instructions (~70 % of the VALU pipe at 2 waves per SIMD), not by HBM
+// or the matrix pipe — see DESIGN.md.
 #include "common.h"
 #include "triplane_tap.h"
 
