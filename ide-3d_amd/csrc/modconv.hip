@@ -1226,7 +1226,10 @@ static int resolve_arith(int a) { return (a == 1 || a == 3 || a == 6 || a == 16)
 
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
-    const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= 12 && p.w_ >= 12 && !mc_env().no_allcls;
+    // all-class form from 4 x 4 maps on (round 3: the per-class form took 65 / 78 us for the 0.3-GFLOP layers at 4^2 / 8^2; 962 -> 974-981
+    // frames/s; IDE3D_MODCONV_ALLCLS_MIN=12 restores the old threshold)
+    static const int allcls_min = getenv("IDE3D_MODCONV_ALLCLS_MIN") ? atoi(getenv("IDE3D_MODCONV_ALLCLS_MIN")) : 4;
+    const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= allcls_min && p.w_ >= allcls_min && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout);
     if (allcls && pl.bm == 128) {

@@ -500,10 +500,12 @@ def test_modconv2d_against_conv2d(gpu_device, n, cin, cout, h, w, k):
     assert_close(y, ref.float(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), what=f'modconv {n, cin, cout, h, w, k}')
 
 
-@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 8, 16, 4, 4), (1, 20, 150, 9, 13), (4, 512, 512, 8, 8), (2, 64, 32, 33, 20), (3, 12, 130, 5, 7)])
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 8, 16, 4, 4), (1, 20, 150, 9, 13), (4, 512, 512, 8, 8), (2, 64, 32, 33, 20), (3, 12, 130, 5, 7),
+                                            (4, 512, 512, 4, 4), (2, 16, 64, 3, 3), (2, 40, 96, 4, 6)])
 def test_modconv2d_transposed_against_conv_transpose2d(gpu_device, n, cin, cout, h, w):
     """mode 2 == conv_transpose2d(x * s, w.transpose(0, 1), stride=2) * d  (conv2d_resample.py:114-125); also covers
-    split-K (512 channels at 8x8) and the 2x8x8 / 8x4x4 pixel tiles."""
+    split-K (512 channels at 8x8 and 4x4: the all-class form starts at 4x4 maps), the per-class form (< 64-row blocks, maps under
+    4 pixels) and the 2x8x8 / 8x4x4 pixel tiles."""
     from torch_utils import hip_plugin
     g = torch.Generator().manual_seed(14)
     x = torch.randn(n, cin, h, w, generator=g)
