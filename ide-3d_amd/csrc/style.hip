@@ -93,16 +93,21 @@ __device__ __forceinline__ void affine_rows_half(const float* __restrict__ wv, c
 // phase A, grid (ceil(cin / STYLE_ROWS), n): styles[n, rows of this block].
 constexpr int STYLE_ROWS = 32;           // 4 waves x 8 rows: cin / 32 x n workgroups (64 for cin = 512, n = 4)
 
-__global__ void __launch_bounds__(256)
-style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
-                    int cin, int wdim, float a_gain, float b_gain, float* __restrict__ styles) {
+__device__ __forceinline__ void style_affine_body(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
+                                                  int cin, int wdim, float a_gain, float b_gain, float* __restrict__ styles, int bx, int img) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_w = lds;
-    const int img = blockIdx.y, i0 = blockIdx.x * STYLE_ROWS;
+    const int i0 = bx * STYLE_ROWS;
     const int rows = min(STYLE_ROWS, cin - i0);
     for (int k = threadIdx.x; k < wdim; k += blockDim.x) s_w[k] = w[(int64_t)img * w_stride + k];
     __syncthreads();
     affine_rows<8>(s_w, A + (int64_t)i0 * wdim, b ? b + i0 : nullptr, rows, wdim, a_gain, b_gain, 1.0f, styles + (int64_t)img * cin + i0);
+}
+
+__global__ void __launch_bounds__(256)
+style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* __restrict__ A, const float* __restrict__ b,
+                    int cin, int wdim, float a_gain, float b_gain, float* __restrict__ styles) {
+    style_affine_body(w, w_stride, A, b, cin, wdim, a_gain, b_gain, styles, blockIdx.x, blockIdx.y);
 }
 
 // phase B, grid ceil(cout / 32): dcoefs[img, o] = rsqrt(sum_i styles[img, i]^2 * wsq_t[i, o] + 1e-8) for every image; wsq_t
@@ -111,15 +116,15 @@ style_affine_kernel(const float* __restrict__ w, int64_t w_stride, const float* 
 // all images (wsq_t is read once, not once per image).
 constexpr int DEMOD_COLS = 32, DEMOD_PARTS = 32, DEMOD_MAX_CI = 512, DEMOD_MAX_N = 8;
 
-__global__ void __launch_bounds__(1024)
-style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq_t, int n, int cin, int cout, float* __restrict__ dcoefs) {
+__device__ __forceinline__ void style_demod_body(const float* __restrict__ styles, const float* __restrict__ wsq_t, int n, int cin, int cout,
+                                                 float* __restrict__ dcoefs, int bx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_s = lds;                                   // [n][cin] squared styles
     float* s_p = lds + (size_t)n * cin;                 // [DEMOD_PARTS][DEMOD_COLS] partial sums of one image
     for (int i = threadIdx.x; i < n * cin; i += blockDim.x) { const float v = styles[i]; s_s[i] = v * v; }
     __syncthreads();
     const int col = threadIdx.x & (DEMOD_COLS - 1), part = threadIdx.x / DEMOD_COLS;
-    const int co = blockIdx.x * DEMOD_COLS + col, coc = min(co, cout - 1);
+    const int co = bx * DEMOD_COLS + col, coc = min(co, cout - 1);
     float acc[DEMOD_MAX_N];
 #pragma unroll
     for (int g = 0; g < DEMOD_MAX_N; ++g) acc[g] = 0.f;
@@ -154,20 +159,23 @@ style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ w
     }
 }
 
+__global__ void __launch_bounds__(1024)
+style_demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq_t, int n, int cin, int cout, float* __restrict__ dcoefs) {
+    style_demod_body(styles, wsq_t, n, cin, cout, dcoefs, blockIdx.x);
+}
+
 // grid: (n, ceil(cin / FOLD_CI)).  Two heads (rgb, seg) sharing w: out[n, o, i] = W_h[o, i] * styles_h[n, i], heads concatenated
 // along o.  A block owns FOLD_CI input channels: it needs only its own styles (FOLD_CI affine rows per head, all in flight
 // at once) and writes the matching columns of every output row.
 constexpr int FOLD_CI = 64;
 
-__global__ void __launch_bounds__(1024)
-fold_heads_kernel(const float* __restrict__ w, int64_t w_stride, int cin, int wdim,
+__device__ __forceinline__ void fold_heads_body(const float* __restrict__ w, int64_t w_stride, int cin, int wdim,
                   const float* __restrict__ A0, const float* __restrict__ b0, const float* __restrict__ W0, int cout0, float gain0,
                   const float* __restrict__ A1, const float* __restrict__ b1, const float* __restrict__ W1, int cout1, float gain1,
-                  float a_gain, float* __restrict__ out) {
+                  float a_gain, float* __restrict__ out, int img, int by) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_w = lds; float* s0 = lds + wdim; float* s1 = s0 + FOLD_CI;
-    const int img = blockIdx.x;
-    const int ci0 = blockIdx.y * FOLD_CI;
+    const int ci0 = by * FOLD_CI;
     const int nci = min(FOLD_CI, cin - ci0);
     for (int k = threadIdx.x; k < wdim; k += blockDim.x) s_w[k] = w[(int64_t)img * w_stride + k];
     __syncthreads();
@@ -182,6 +190,51 @@ fold_heads_kernel(const float* __restrict__ w, int64_t w_stride, int cin, int wd
         const int ci = ci0 + cl;
         o[(int64_t)co * cin + ci] = (co < cout0) ? W0[(int64_t)co * cin + ci] * s0[cl] : W1[(int64_t)(co - cout0) * cin + ci] * s1[cl];
     }
+}
+
+__global__ void __launch_bounds__(1024)
+fold_heads_kernel(const float* __restrict__ w, int64_t w_stride, int cin, int wdim,
+                  const float* __restrict__ A0, const float* __restrict__ b0, const float* __restrict__ W0, int cout0, float gain0,
+                  const float* __restrict__ A1, const float* __restrict__ b1, const float* __restrict__ W1, int cout1, float gain1,
+                  float a_gain, float* __restrict__ out) {
+    fold_heads_body(w, w_stride, cin, wdim, A0, b0, W0, cout0, gain0, A1, b1, W1, cout1, gain1, a_gain, out, blockIdx.x, blockIdx.y);
+}
+
+// ---- all layers of a pass in three launches (round 3) ------------------------------------------------------------------------
+// The 43 launches above (13 + 7 pairs and 7 + 3 head foldings of a 64 -> 512 pass) are 6 - 17 us each and depend only on ws: as
+// separate nodes of the captured graph they run, back to back, BEFORE the first convolution (the graph executor does not start the
+// convolution branch beside them: scripts/step_timeline.py) — ~0.4 ms of a 4.2 ms pass.  The batched forms take the same per-layer
+// arguments as a table in the kernel arguments and map a flat block index to (layer, block): same code per block, same results.
+struct StyleBatch { ide3d_style_job job[IDE3D_STYLE_BATCH_MAX]; int blk0[IDE3D_STYLE_BATCH_MAX + 1]; int njobs; };
+struct FoldBatch { ide3d_fold_job job[IDE3D_STYLE_BATCH_MAX]; int blk0[IDE3D_STYLE_BATCH_MAX + 1]; int njobs; };
+
+template <class B>
+__device__ __forceinline__ int batch_job(const B& b, int bx) {
+    int j = 0;
+    while (j + 1 < b.njobs && bx >= b.blk0[j + 1]) ++j;
+    return j;
+}
+
+__global__ void __launch_bounds__(256)
+style_affine_batch_kernel(const StyleBatch b, int wdim) {
+    const int j = batch_job(b, blockIdx.x);
+    const ide3d_style_job& q = b.job[j];
+    style_affine_body(q.w, q.w_stride, q.affine_w, q.affine_b, q.cin, wdim, q.affine_gain, q.bias_gain, q.styles, blockIdx.x - b.blk0[j], blockIdx.y);
+}
+
+__global__ void __launch_bounds__(1024)
+style_demod_batch_kernel(const StyleBatch b, int n) {
+    const int j = batch_job(b, blockIdx.x);
+    const ide3d_style_job& q = b.job[j];
+    style_demod_body(q.styles, q.wsq_t, n, q.cin, q.cout, q.dcoefs, blockIdx.x - b.blk0[j]);
+}
+
+__global__ void __launch_bounds__(1024)
+fold_heads_batch_kernel(const FoldBatch b, int wdim) {
+    const int j = batch_job(b, blockIdx.y);
+    const ide3d_fold_job& q = b.job[j];
+    fold_heads_body(q.w, q.w_stride, q.cin, wdim, q.a0, q.b0, q.w0, q.cout0, q.gain0, q.a1, q.b1, q.w1, q.cout1, q.gain1, q.affine_gain, q.out,
+                    blockIdx.x, blockIdx.y - b.blk0[j]);
 }
 
 }  // namespace ide3d
@@ -221,5 +274,48 @@ extern "C" int ide3d_fold_heads(const float* w, int64_t w_stride, int32_t n, int
     hipLaunchKernelGGL(fold_heads_kernel, dim3(n, cdiv(cin, FOLD_CI)), dim3(1024), lds, (hipStream_t)stream,
                        w, w_stride, cin, wdim, a0, b0, w0, cout0, gain0, a1, b1, w1, cout1, gain1, affine_gain, out);
     IDE3D_CHECK_LAUNCH("fold_heads");
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_style_demod_batch(const ide3d_style_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(jobs && njobs > 0 && njobs <= IDE3D_STYLE_BATCH_MAX, "style_demod_batch: 1..%d jobs", IDE3D_STYLE_BATCH_MAX);
+    IDE3D_CHECK_ARG(n > 0 && n <= DEMOD_MAX_N && wdim > 0, "style_demod_batch: 1..%d images", DEMOD_MAX_N);
+    IDE3D_CHECK_ARG((size_t)wdim * sizeof(float) <= 60 * 1024, "style_demod_batch: w_dim too large for LDS staging");
+    StyleBatch a{}, d{};
+    int na = 0, nd = 0, max_cin = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const ide3d_style_job& q = jobs[j];
+        IDE3D_CHECK_ARG(q.w && q.affine_w && q.styles && q.cin > 0, "style_demod_batch: job %d: null pointer / bad shape", j);
+        IDE3D_CHECK_ARG(q.dcoefs == nullptr || (q.wsq_t != nullptr && q.cout > 0), "style_demod_batch: job %d: dcoefs needs wsq_t", j);
+        a.job[j] = q; a.blk0[j] = na; na += cdiv(q.cin, STYLE_ROWS);
+        if (q.dcoefs) { d.job[d.njobs] = q; d.blk0[d.njobs] = nd; nd += cdiv(q.cout, DEMOD_COLS); ++d.njobs; if (q.cin > max_cin) max_cin = q.cin; }
+    }
+    a.njobs = njobs; a.blk0[njobs] = na; d.blk0[d.njobs] = nd;
+    IDE3D_CHECK_ARG(((size_t)n * max_cin + DEMOD_PARTS * DEMOD_COLS) * sizeof(float) <= 60 * 1024, "style_demod_batch: cin too large for LDS staging");
+    hipLaunchKernelGGL(style_affine_batch_kernel, dim3(na, n), dim3(256), (size_t)wdim * sizeof(float), (hipStream_t)stream, a, wdim);
+    if (d.njobs)
+        hipLaunchKernelGGL(style_demod_batch_kernel, dim3(nd), dim3(1024), ((size_t)n * max_cin + DEMOD_PARTS * DEMOD_COLS) * sizeof(float),
+                           (hipStream_t)stream, d, n);
+    IDE3D_CHECK_LAUNCH("style_demod_batch");
+    return IDE3D_OK;
+}
+
+extern "C" int ide3d_fold_heads_batch(const ide3d_fold_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(jobs && njobs > 0 && njobs <= IDE3D_STYLE_BATCH_MAX, "fold_heads_batch: 1..%d jobs", IDE3D_STYLE_BATCH_MAX);
+    IDE3D_CHECK_ARG(n > 0 && wdim > 0, "fold_heads_batch: bad shape");
+    const size_t lds = ((size_t)wdim + 2 * FOLD_CI) * sizeof(float);
+    IDE3D_CHECK_ARG(lds <= 60 * 1024, "fold_heads_batch: w_dim too large for LDS staging");
+    FoldBatch b{};
+    int nb = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const ide3d_fold_job& q = jobs[j];
+        IDE3D_CHECK_ARG(q.w && q.a0 && q.w0 && q.a1 && q.w1 && q.out && q.cin > 0 && q.cout0 > 0 && q.cout1 > 0, "fold_heads_batch: job %d: null pointer / bad shape", j);
+        b.job[j] = q; b.blk0[j] = nb; nb += cdiv(q.cin, FOLD_CI);
+    }
+    b.njobs = njobs; b.blk0[njobs] = nb;
+    hipLaunchKernelGGL(fold_heads_batch_kernel, dim3(n, nb), dim3(1024), lds, (hipStream_t)stream, b, wdim);
+    IDE3D_CHECK_LAUNCH("fold_heads_batch");
     return IDE3D_OK;
 }

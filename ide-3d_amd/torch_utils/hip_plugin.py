@@ -20,7 +20,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 3
+_ABI_VERSION = 4
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -123,6 +123,30 @@ class _ModconvParams(ctypes.Structure):
     ]
 
 
+STYLE_BATCH_MAX = 24        # IDE3D_STYLE_BATCH_MAX
+
+
+class _StyleJob(ctypes.Structure):
+    _fields_ = [
+        ('w', ctypes.c_void_p), ('w_stride', ctypes.c_int64),
+        ('affine_w', ctypes.c_void_p), ('affine_b', ctypes.c_void_p),
+        ('wsq_t', ctypes.c_void_p),
+        ('cin', ctypes.c_int32), ('cout', ctypes.c_int32),
+        ('affine_gain', ctypes.c_float), ('bias_gain', ctypes.c_float),
+        ('styles', ctypes.c_void_p), ('dcoefs', ctypes.c_void_p),
+    ]
+
+
+class _FoldJob(ctypes.Structure):
+    _fields_ = [
+        ('w', ctypes.c_void_p), ('w_stride', ctypes.c_int64),
+        ('cin', ctypes.c_int32), ('affine_gain', ctypes.c_float),
+        ('a0', ctypes.c_void_p), ('b0', ctypes.c_void_p), ('w0', ctypes.c_void_p), ('cout0', ctypes.c_int32), ('gain0', ctypes.c_float),
+        ('a1', ctypes.c_void_p), ('b1', ctypes.c_void_p), ('w1', ctypes.c_void_p), ('cout1', ctypes.c_int32), ('gain1', ctypes.c_float),
+        ('out', ctypes.c_void_p),
+    ]
+
+
 class _MappingParams(ctypes.Structure):
     _fields_ = [
         ('z', ctypes.c_void_p), ('c', ctypes.c_void_p), ('embed_w', ctypes.c_void_p), ('embed_b', ctypes.c_void_p),
@@ -206,6 +230,8 @@ def load():
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
             'ide3d_style_demod': [vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp],
             'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
+            'ide3d_style_demod_batch': [ctypes.POINTER(_StyleJob), i32, i32, i32, vp],
+            'ide3d_fold_heads_batch': [ctypes.POINTER(_FoldJob), i32, i32, i32, vp],
             'ide3d_mapping': [ctypes.POINTER(_MappingParams), vp],
             'ide3d_mapping_workspace_bytes': [],
             'ide3d_mapping_supported': [],
@@ -226,6 +252,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
+    'ide3d_style_demod_batch', 'ide3d_fold_heads_batch',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
 )
 
@@ -884,6 +911,90 @@ class StylePlugin:
                                          _ptr(a1), _ptr(b1), _ptr(w1), cout1, float(gain1), _ptr(out), _stream(w))
         _check(rc, 'fold_heads')
         return out
+
+    @staticmethod
+    def style_demod_batch(jobs):
+        """All modulated layers of a pass in two launches.  jobs: [(w, affine_w, affine_b, affine_gain, bias_gain, wsq_t or None)]
+        with w [n, wdim] (unit inner stride) -> [(styles [n, cin], dcoefs [n, cout] or None)], views of two buffers.  Same per-layer
+        code as `style_demod`: bit-identical.  Returns None when the batch form does not apply (n > 8, > STYLE_BATCH_MAX layers handled
+        by chunking)."""
+        if not jobs:
+            return []
+        w0 = jobs[0][0]
+        n, wdim = w0.shape
+        if n > 8:
+            return None
+        dev = w0.device
+        tot_s = sum(j[1].shape[0] for j in jobs)
+        tot_d = sum(j[5].shape[1] for j in jobs if j[5] is not None)
+        sbuf = torch.empty([n * tot_s], dtype=torch.float32, device=dev)
+        dbuf = torch.empty([max(n * tot_d, 1)], dtype=torch.float32, device=dev)
+        arr = (_StyleJob * len(jobs))()
+        outs, so, do = [], 0, 0
+        for k, (w, aw, ab, again, bgain, wsq_t) in enumerate(jobs):
+            _require(w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1 and tuple(w.shape) == (n, wdim) and w.device == dev,
+                     'style_demod_batch: every w must be float32 [n, wdim] with unit inner stride on one device')
+            cin = aw.shape[0]
+            _require(aw.is_contiguous() and aw.shape[1] == wdim and aw.dtype == torch.float32 and aw.device == dev, 'style_demod_batch: affine weight must be contiguous float32 [cin, wdim]')
+            _require(ab is None or (ab.is_contiguous() and ab.numel() == cin and ab.device == dev), 'style_demod_batch: affine bias must be contiguous [cin]')
+            styles = sbuf[so:so + n * cin].view(n, cin); so += n * cin
+            dco, cout = None, 0
+            if wsq_t is not None:
+                _require(wsq_t.is_contiguous() and wsq_t.shape[0] == cin and wsq_t.device == dev, 'style_demod_batch: wsq_t must be contiguous [cin, cout]')
+                cout = wsq_t.shape[1]
+                dco = dbuf[do:do + n * cout].view(n, cout); do += n * cout
+            j = arr[k]
+            j.w, j.w_stride = w.data_ptr(), w.stride(0)
+            j.affine_w, j.affine_b = aw.data_ptr(), (ab.data_ptr() if ab is not None else None)
+            j.wsq_t = wsq_t.data_ptr() if wsq_t is not None else None
+            j.cin, j.cout, j.affine_gain, j.bias_gain = cin, cout, float(again), float(bgain)
+            j.styles, j.dcoefs = styles.data_ptr(), (dco.data_ptr() if dco is not None else None)
+            outs.append((styles, dco))
+        lib = load()
+        with torch.cuda.device(dev):
+            for k0 in range(0, len(jobs), STYLE_BATCH_MAX):
+                cnt = min(STYLE_BATCH_MAX, len(jobs) - k0)
+                rc = lib.ide3d_style_demod_batch(ctypes.cast(ctypes.byref(arr, k0 * ctypes.sizeof(_StyleJob)), ctypes.POINTER(_StyleJob)),
+                                                 cnt, n, wdim, _stream(w0))
+                _check(rc, 'style_demod_batch')
+        return outs
+
+    @staticmethod
+    def fold_heads_batch(jobs):
+        """All dual heads of a pass in one launch.  jobs: [(w, affine_gain, a0, b0, w0, gain0, a1, b1, w1, gain1)] (arguments of
+        `fold_heads`) -> [out [n, cout0 + cout1, cin, 1, 1]], views of one buffer; bit-identical to `fold_heads`."""
+        if not jobs:
+            return []
+        w_0 = jobs[0][0]
+        n, wdim = w_0.shape
+        dev = w_0.device
+        sizes = [(j[4].shape[0] + j[8].shape[0]) * j[4].shape[1] for j in jobs]
+        buf = torch.empty([n * sum(sizes)], dtype=torch.float32, device=dev)
+        arr = (_FoldJob * len(jobs))()
+        outs, off = [], 0
+        for k, (w, again, a0, b0, w0, g0, a1, b1, w1, g1) in enumerate(jobs):
+            _require(w.is_cuda and w.dtype == torch.float32 and w.ndim == 2 and w.stride(1) == 1 and tuple(w.shape) == (n, wdim) and w.device == dev,
+                     'fold_heads_batch: every w must be float32 [n, wdim] with unit inner stride on one device')
+            for t in (a0, b0, w0, a1, b1, w1):
+                _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev, 'fold_heads_batch: contiguous float32 CUDA tensors required')
+            cout0, cin = w0.shape[0], w0.shape[1]
+            cout1 = w1.shape[0]
+            _require(w1.shape[1] == cin and a0.shape == (cin, wdim) and a1.shape == (cin, wdim), 'fold_heads_batch: head shapes do not agree')
+            out = buf[off:off + n * sizes[k]].view(n, cout0 + cout1, cin, 1, 1); off += n * sizes[k]
+            j = arr[k]
+            j.w, j.w_stride, j.cin, j.affine_gain = w.data_ptr(), w.stride(0), cin, float(again)
+            j.a0, j.b0, j.w0, j.cout0, j.gain0 = a0.data_ptr(), b0.data_ptr(), w0.data_ptr(), cout0, float(g0)
+            j.a1, j.b1, j.w1, j.cout1, j.gain1 = a1.data_ptr(), b1.data_ptr(), w1.data_ptr(), cout1, float(g1)
+            j.out = out.data_ptr()
+            outs.append(out)
+        lib = load()
+        with torch.cuda.device(dev):
+            for k0 in range(0, len(jobs), STYLE_BATCH_MAX):
+                cnt = min(STYLE_BATCH_MAX, len(jobs) - k0)
+                rc = lib.ide3d_fold_heads_batch(ctypes.cast(ctypes.byref(arr, k0 * ctypes.sizeof(_FoldJob)), ctypes.POINTER(_FoldJob)),
+                                                cnt, n, wdim, _stream(w_0))
+                _check(rc, 'fold_heads_batch')
+        return outs
 
 
 class FramePlugin:

@@ -118,26 +118,60 @@ def _style_plan(block, ws_block):
 
 
 def prefetch_styles(blocks_and_ws, side_stream):
-    """Run the style kernels of all layers of `blocks_and_ws` = [(block, ws_block), ...] on `side_stream`.  The results
-    live in a table owned by this call (thread-local, replaced per pass): two generators rendering on different threads
-    never see each other's entries.  Always pair with `finish_prefetch` in a try / finally."""
+    """Compute the styles, demodulation coefficients and folded head weights of all layers of `blocks_and_ws` =
+    [(block, ws_block), ...] up front on `side_stream`: three batched launches (csrc/style.hip: all affines, all demodulations, all
+    head foldings) where the batch form applies, one launch pair / one launch per layer otherwise.  The results live in a table owned
+    by this call (thread-local, replaced per pass): two generators rendering on different threads never see each other's entries.
+    Always pair with `finish_prefetch` in a try / finally.
+
+    Why batched: as 43 separate nodes of a captured graph these 6 - 17 us launches run back to back BEFORE the first convolution of the
+    pass — the graph executor does not start the convolution branch beside them (scripts/step_timeline.py: the first convolution
+    started ~0.4 ms after the mapping network had finished) — so the pass pays for their count, not for their work."""
     _prefetched = _tls.prefetched = {}
     main = torch.cuda.current_stream()
     side_stream.wait_stream(main)
     with torch.cuda.stream(side_stream):
-        for block, ws_block in blocks_and_ws:
-            for kind, mod, w in _style_plan(block, ws_block):
-                if kind == 'conv':
-                    res = _styles_and_dcoefs(mod.affine, w, mod.weight, True)
-                    key = id(mod.affine)
-                else:
-                    res = _folded_head_weights(mod.torgb, mod.toseg, w)
-                    key = id(mod.torgb)
-                if res is None:
-                    continue
-                ev = torch.cuda.Event()
-                ev.record(side_stream)
-                _prefetched[key] = (w.data_ptr(), res, ev)
+        plan = [(kind, mod, w) for block, ws_block in blocks_and_ws for kind, mod, w in _style_plan(block, ws_block)]
+        conv_jobs, head_jobs = [], []
+        batched = bool(plan) and _style_init() and not os.environ.get('IDE3D_NO_STYLE_BATCH')
+        for kind, mod, w in plan:
+            if kind == 'conv':
+                a = mod.affine
+                ok = (batched and _inference_on_gpu(w, a.weight, mod.weight) and w.ndim == 2 and w.stride(1) == 1 and w.shape[0] <= 8
+                      and a.activation == 'linear' and a.bias is not None)
+                if ok:
+                    conv_jobs.append((mod, w))
+            else:
+                tr, ts = mod.torgb, mod.toseg
+                ok = (batched and w.ndim == 2 and w.stride(1) == 1 and tr.weight.shape[2] == 1 and _inference_on_gpu(w, tr.weight, ts.weight))
+                if ok:
+                    head_jobs.append((mod, w))
+        done = set()
+        if conv_jobs:
+            res = _style_plugin.style_demod_batch([(w, m.affine.weight, m.affine.bias, m.affine.weight_gain, m.affine.bias_gain, _wsq_t(m.weight))
+                                                   for m, w in conv_jobs])
+            if res is not None:
+                ev = torch.cuda.Event(); ev.record(side_stream)
+                for (m, w), r in zip(conv_jobs, res):
+                    _prefetched[id(m.affine)] = (w.data_ptr(), r, ev); done.add(id(m.affine))
+        if head_jobs:
+            res = _style_plugin.fold_heads_batch([(w, b.torgb.affine.weight_gain,
+                                                   b.torgb.affine.weight, b.torgb.affine.bias, b.torgb.weight.reshape(b.torgb.weight.shape[0], -1), b.torgb.weight_gain,
+                                                   b.toseg.affine.weight, b.toseg.affine.bias, b.toseg.weight.reshape(b.toseg.weight.shape[0], -1), b.toseg.weight_gain)
+                                                  for b, w in head_jobs])
+            ev = torch.cuda.Event(); ev.record(side_stream)
+            for (b, w), r in zip(head_jobs, res):
+                _prefetched[id(b.torgb)] = (w.data_ptr(), r, ev); done.add(id(b.torgb))
+        for kind, mod, w in plan:                       # whatever the batch form did not take: per layer, as before
+            key = id(mod.affine) if kind == 'conv' else id(mod.torgb)
+            if key in done:
+                continue
+            res = _styles_and_dcoefs(mod.affine, w, mod.weight, True) if kind == 'conv' else _folded_head_weights(mod.torgb, mod.toseg, w)
+            if res is None:
+                continue
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+            _prefetched[key] = (w.data_ptr(), res, ev)
 
 
 def finish_prefetch(side_stream):

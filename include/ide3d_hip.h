@@ -425,6 +425,32 @@ int ide3d_fold_heads(const float* w, int64_t w_stride, int32_t n, int32_t cin, i
                      const float* a1, const float* b1, const float* w1, int32_t cout1, float gain1,
                      float* out, void* stream);
 
+/*
+ * The two entry points above for ALL layers of a synthesis pass at once: every modulated layer's affine + demodulation in two
+ * launches, every block's head folding in one (round 3: as 43 separate nodes of a captured graph they delay the first convolution
+ * of the pass by ~0.4 ms).  A job carries exactly the per-layer arguments of ide3d_style_demod / ide3d_fold_heads; n (images) and
+ * wdim are shared by the jobs.  Same code per block as the per-layer kernels: bit-identical results.  njobs <= IDE3D_STYLE_BATCH_MAX;
+ * ide3d_style_demod_batch: n <= 8.
+ */
+#define IDE3D_STYLE_BATCH_MAX 24
+typedef struct ide3d_style_job {
+    const float* w; int64_t w_stride;                 /* this layer's latent of image 0, stride to the next image */
+    const float* affine_w; const float* affine_b;     /* [cin, wdim], [cin] or NULL */
+    const float* wsq_t;                               /* [cin, cout] or NULL (no demodulation) */
+    int32_t cin, cout;
+    float affine_gain, bias_gain;
+    float* styles; float* dcoefs;                     /* [n, cin]; [n, cout] or NULL */
+} ide3d_style_job;
+typedef struct ide3d_fold_job {
+    const float* w; int64_t w_stride;
+    int32_t cin; float affine_gain;
+    const float *a0, *b0, *w0; int32_t cout0; float gain0;
+    const float *a1, *b1, *w1; int32_t cout1; float gain1;
+    float* out;                                       /* [n, cout0 + cout1, cin] */
+} ide3d_fold_job;
+int ide3d_style_demod_batch(const ide3d_style_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream);
+int ide3d_fold_heads_batch(const ide3d_fold_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream);
+
 /* ---- output post-processing -------------------------------------------- */
 /* ---- mapping network ---------------------------------------------------------------------- */
 /*

@@ -842,3 +842,39 @@ def test_mapping_network_single_launch(golden, gpu_device):
         assert _calls('mapping') == before, 'n = 9 > 8 takes the generic path'
         assert_close(got, M(z64, None), rtol=1e-4, atol=1e-5, what='generic path')
         assert_close(Mg(z64[:4].to(gpu_device), None), M(z64[:4], None), rtol=1e-4, atol=1e-5, what='float64 z')
+
+def test_style_batch_equals_per_layer(gpu_device):
+    """ide3d_style_demod_batch / ide3d_fold_heads_batch (all layers of a pass in 2 + 1 launches) == the per-layer entry points, bit for
+    bit: mixed channel counts, a layer without demodulation, strided latents (ws[:, i] views), more jobs than one launch holds."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(31)
+    n, wdim = 4, 512
+    ws = torch.randn(n, 30, wdim, generator=g).to(gpu_device)
+    P = hip_plugin.StylePlugin
+    jobs, ref = [], []
+    shapes = [(512, 512), (512, 256), (256, 128), (96, 64), (40, 0), (64, 64)] * 5          # 30 jobs > STYLE_BATCH_MAX; cout 0 = no demodulation
+    for k, (cin, cout) in enumerate(shapes):
+        aw = (torch.randn(cin, wdim, generator=g) * 0.05).to(gpu_device)
+        ab = torch.randn(cin, generator=g).to(gpu_device)
+        wsq = (torch.rand(cin, cout, generator=g) + 0.1).to(gpu_device) if cout else None
+        w = ws[:, k]
+        jobs.append((w, aw, ab, 1 / math.sqrt(wdim), 1.0, wsq))
+        ref.append(P.style_demod(w, aw, ab, 1 / math.sqrt(wdim), 1.0, wsq))
+    before = hip_plugin.CALLS.get('style_demod_batch', 0)
+    got = P.style_demod_batch(jobs)
+    assert hip_plugin.CALLS.get('style_demod_batch', 0) - before == 2            # 24 + 6 jobs
+    for (s0, d0), (s1, d1) in zip(ref, got):
+        assert torch.equal(s0, s1)
+        assert (d0 is None and d1 is None) or torch.equal(d0, d1)
+    fjobs, fref = [], []
+    for k, (cin, c0, c1) in enumerate([(512, 96, 96), (256, 96, 96), (128, 96, 96), (64, 3, 19), (128, 3, 19), (32, 3, 19)]):
+        a0 = (torch.randn(cin, wdim, generator=g) * 0.05).to(gpu_device); b0 = torch.randn(cin, generator=g).to(gpu_device)
+        a1 = (torch.randn(cin, wdim, generator=g) * 0.05).to(gpu_device); b1 = torch.randn(cin, generator=g).to(gpu_device)
+        w0 = torch.randn(c0, cin, generator=g).to(gpu_device); w1 = torch.randn(c1, cin, generator=g).to(gpu_device)
+        w = ws[:, 20 + k]
+        args = (w, 1 / math.sqrt(wdim), a0, b0, w0, 1 / math.sqrt(cin), a1, b1, w1, 1 / math.sqrt(cin))
+        fjobs.append(args)
+        fref.append(P.fold_heads(*args))
+    fgot = P.fold_heads_batch(fjobs)
+    for r0, r1 in zip(fref, fgot):
+        assert r0.shape == r1.shape and torch.equal(r0, r1)
