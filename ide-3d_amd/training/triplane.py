@@ -126,7 +126,13 @@ class TriplaneDecoder(torch.nn.Module):
         """Effective (gain-folded) weights in the layout `ide3d_render_rays` expects."""
         out = {}
         for name, layer in (('geo_w0', self.geo0), ('geo_w1', self.geo1), ('tex_w0', self.tex0), ('tex_w1', self.tex1)):
-            w, b = layer.effective(torch.float32)
+            if layer.weight.is_cuda and layer.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and layer.weight.requires_grad):
+                # inference: the gain-folded copies are formed once per (tensor, version), not by four element-wise launches per call
+                # (a density query of extract_shapes.py's chunk loop is ONE other launch)
+                w = networks._scaled_weight(layer.weight, layer.weight_gain)
+                b = layer.bias if layer.bias_gain == 1 else networks._scaled_weight(layer.bias, layer.bias_gain)
+            else:
+                w, b = layer.effective(torch.float32)
             out[name] = w.contiguous()
             out[name.replace('_w', '_b')] = b.contiguous()
         return out
