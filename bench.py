@@ -342,8 +342,12 @@ def main():
         seeds = [(i * world + (rank if r is None else r)) * BATCH + j for j in range(BATCH)]
         z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(spec.z_dim) for s in seeds]))
         # pinned + non_blocking: a pageable host-to-device copy blocks the host until the stream has drained, i.e. until the previous
-        # step has finished, and the GPU then idles for the ~0.1 ms the host needs to enqueue the next step (scripts/step_timeline.py)
-        return z.to(device) if cpu else z.pin_memory().to(device, non_blocking=True)
+        # step has finished, and the GPU then idles for the ~0.1 ms the host needs to enqueue the next step (scripts/step_timeline.py).
+        # The graphed renderer copies a host tensor straight into its static input buffer (one launch instead of copy + conversion).
+        if cpu:
+            return z.to(device)
+        z = z.float().pin_memory()
+        return z if graphed is not None else z.to(device, non_blocking=True)
 
     def step(i, blocking=False, jitter=None):
         img, seg = render(latents(i), cond, cams, jitter)
