@@ -433,6 +433,19 @@ def _folded_head_weights(torgb, toseg, w):
                                     toseg.affine.weight, toseg.affine.bias, toseg.weight.reshape(toseg.weight.shape[0], -1), toseg.weight_gain)
 
 
+def _adjacent_views(a, b):
+    """The tensor `t` with a = t[:, :ca] and b = t[:, ca:] if a and b are exactly that (views of one [N, ca + cb, H, W] tensor), else None."""
+    if a is None or b is None or a._base is None or a._base is not b._base:
+        return None
+    t = a._base
+    if (t.ndim != 4 or a.ndim != 4 or b.ndim != 4 or not t.is_contiguous() or t.shape[1] != a.shape[1] + b.shape[1]
+            or a.shape[0] != t.shape[0] or a.shape[2:] != t.shape[2:] or b.shape[0] != t.shape[0] or b.shape[2:] != t.shape[2:]
+            or a.stride() != t.stride() or b.stride() != t.stride()
+            or a.data_ptr() != t.data_ptr() or b.data_ptr() != t.data_ptr() + a.shape[1] * t.stride(1) * t.element_size()):
+        return None
+    return t
+
+
 def _dual_head(x, torgb, toseg, w):
     """toRGB + toSeg of a dual-path block (reference networks.py:1109,1130) as ONE 1x1 implicit-GEMM launch.
     The two heads modulate with different styles, so the styles are folded into per-image weights
@@ -872,8 +885,16 @@ class SegSynthesisBlock(torch.nn.Module):
                 else:
                     y = self.torgb(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
                     y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
-                img = self._accumulate(img_lo, img, y)
-                seg = self._accumulate(seg_lo, seg, y_seg)
+                lo_both, y_both = _adjacent_views(img_lo, seg_lo), _adjacent_views(y, y_seg)
+                if (lo_both is not None and y_both is not None and img is None and seg is None and not getattr(self, 'skip_channels_last', False)
+                        and not os.environ.get('IDE3D_NO_SKIP_MERGE')):
+                    # both skip images in ONE up-sample + add launch: they are channel ranges of one tensor (the dual head's output,
+                    # the previous block's accumulation) all the way through the backbone
+                    both = self._accumulate(lo_both, None, y_both)
+                    img, seg = both[:, :y.shape[1]], both[:, y.shape[1]:]
+                else:
+                    img = self._accumulate(img_lo, img, y)
+                    seg = self._accumulate(seg_lo, seg, y_seg)
         assert x.dtype == dtype
         if out_dtype != dtype:
             x = x.to(out_dtype)
