@@ -15,13 +15,18 @@ Timing: W untimed warm-up steps, then `--blocks` (default 5) timed blocks of EXA
 `torch.cuda.synchronize()` on both sides, MAX over ranks per block; `value` / `ms_per_step` are the MEDIAN block (min / max
 are reported next to it: box-to-box and run-to-run spread is a few per cent).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline        the tri-plane gather kernel (the kernel BASELINE's metric names): algorithmic bytes / HIP-event time
-  roofline_extra  the same for every other hand-written kernel at its config-2 shape (scripts/kernel_rooflines.py), N = 1 only
-  cpu_baseline    the CPU oracle ("port" of the reference's PyTorch CPU path) timed on the host cores, rank 0, N = 1 only
-  parity_ok       after the timed region the SAME captured graph renders fixed inputs (seeds 0-3, fixed jitter) and the frames are
-                  compared with the oracle fixture tests/golden/bench_parity.npz (oracle/make_bench_parity.py); with the
-                  cpu_baseline leg on, the oracle frame computed there is compared live as well (`parity_live`)
+Rank 0 prints ONE COMPACT JSON line (< 4 KB, contract in the task statement; tests/test_bench_launcher_cpu.py checks the size and a
+strict `json.loads`).  `value` is measured with the LIBRARY-DEFAULT convolution arithmetic (exact fp32 products) — what a drop-in caller
+gets; the opt-in split arithmetics are listed next to it in `by_conv_arithmetic`.  Extra objects in the line:
+  roofline         the tri-plane gather kernel (the kernel BASELINE's metric names): algorithmic bytes / HIP-event time
+  roofline_worst   the five hand-written kernels furthest below their roofline at their config-2 shapes (scripts/kernel_rooflines.py)
+  cpu_baseline     the CPU oracle ("port" of the reference's PyTorch CPU path) timed on the host cores, rank 0, N = 1 only
+  dropin_eager_b1  the reference's gen_images.py:88-114 loop shape: batch 1, eager launches, default arithmetic
+  parity_ok        after the timed region the SAME captured graph renders fixed inputs (seeds 0-3, fixed jitter) and the frames are
+                   compared with the oracle fixture tests/golden/bench_parity.npz (oracle/make_bench_parity.py); with the
+                   cpu_baseline leg on, the oracle frame computed there is compared live as well (`parity_live`)
+The FULL record (every kernel's roofline row, the arithmetic sweep with timings, thread probes, notes) goes to
+`gpurun_out/bench_full.json` and, pretty-printed, to stderr — never to stdout.
 """
 
 import argparse
@@ -44,10 +49,12 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY = 6.29e12           # B/s, measured copy ceiling (same guide)
 FP32_MFMA_PEAK = 157.3e12    # FLOP/s
 BATCH = 4                    # seeds per rank per step (BASELINE config 2)
-PROFILE_ROUND = 'round3'
+PROFILE_ROUND = 'round4'
 YAWS = (-0.5, 0.0, 0.5, 0.25)
 PARITY_JITTER_SEED = 11      # = oracle/make_bench_parity.py
-HEADLINE_ARITH = 'f16x3'     # fp32-grade (tests/test_gpu_conv_arith.py, test_bench_parity_fixture_per_conv_arithmetic); `value_fp32_exact` is reported next to it
+HEADLINE_ARITH = 'default'   # the library default (`ide3d_get_conv_arithmetic()` of a fresh process: exact fp32 products) - what a drop-in caller runs
+PARITY_TOL = 2e-5            # of the image / logit scale; measured 2-4e-6 in every arithmetic but bf16x3 (1.4e-5)
+LINE_LIMIT = 4096            # bytes of the ONE stdout line (round 3's 20 KB line was not parsed by the driver)
 
 
 # ---- launcher ----------------------------------------------------------------------------------------------------------------
@@ -137,7 +144,7 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
     # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
     traffic, traffic_source = None, None
-    for rnd in (PROFILE_ROUND, 'round2', 'round1'):
+    for rnd in (PROFILE_ROUND, 'round3', 'round2', 'round1'):
         pmc = os.path.join(ROOT, 'profiles', rnd, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
         if os.path.isfile(pmc):
             rec = json.load(open(pmc))
@@ -219,7 +226,7 @@ def parity_inputs():
     return z, cams, cond, jit
 
 
-def check_parity(render, device, tol=2e-3):
+def check_parity(render, device, tol=PARITY_TOL):
     """Render the fixed parity inputs through `render` (the benchmarked callable) and compare with the oracle fixture."""
     path = os.path.join(ROOT, 'tests', 'golden', 'bench_parity.npz')
     z, cams, cond, jit = parity_inputs()
@@ -236,6 +243,70 @@ def check_parity(render, device, tol=2e-3):
     return rec, (img, seg)
 
 
+def _finite(o):
+    """NaN / +-inf -> None (strict JSON has neither), recursively."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float('inf') else None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _finite(o.item())
+    return o
+
+
+OPTIONAL_KEYS = ('roofline_worst', 'dropin_eager_b1', 'parity_live', 'gather_overlap', 'frames_per_s_by_rank', 'timing', 'by_conv_arithmetic', 'parity')
+
+
+def compact_line(out, limit=None):
+    """The ONE stdout line: strict JSON (ASCII, no NaN / Infinity), at most LINE_LIMIT bytes.  Should it ever grow past the limit, the
+    optional objects are dropped one by one (the contract keys, `roofline` and `cpu_baseline` stay) — round 3's 20 KB line was not parsed."""
+    limit = LINE_LIMIT if limit is None else limit
+    out = _finite(dict(out))
+    line = json.dumps(out, allow_nan=False, ensure_ascii=True, separators=(',', ':'))
+    dropped = []
+    for k in OPTIONAL_KEYS:
+        if len(line) <= limit:
+            break
+        if k in out:
+            out.pop(k); dropped.append(k)
+            out['dropped_for_size'] = dropped
+            line = json.dumps(out, allow_nan=False, ensure_ascii=True, separators=(',', ':'))
+    assert len(line) <= limit, f'bench line is {len(line)} bytes'
+    return line
+
+
+def dropin_eager_b1(G, device, palette, images=24, warm=4):
+    """What a drop-in caller of the reference's gen_images.py:88-114 gets: one seed at a time (batch 1), eager launches (no hipGraph),
+    the library-default arithmetic, `G.mapping` -> `G.synthesis(return_seg=True)` -> uint8 RGB | coloured seg frame, host latents per seed.
+    Timed over `images` seeds between two synchronisations."""
+    from training import triplane
+    from training import distributed_render as dr
+    cond = triplane.conditioning_label(device)
+    cam = triplane.camera_label(0.0, device=device)
+
+    def one(seed):
+        z = torch.from_numpy(np.random.RandomState(seed).randn(1, G.z_dim)).to(device).float()
+        with torch.no_grad():
+            ws = G.mapping(z, cond)
+            img, seg = G.synthesis(ws, c=cam, noise_mode='const', return_seg=True)
+            return dr.frames_u8(img, seg, palette)
+
+    for s in range(warm):
+        one(10_000 + s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(images):
+        one(s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'frames_per_s': round(images / dt, 1), 'ms_per_image': round(dt / images * 1e3, 3), 'images': images,
+            'what': 'gen_images.py loop shape: batch 1, eager launches, library-default arithmetic'}
+
+
+ARITH_DTYPE_SHORT = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convs: f16x3 split, f32 accumulate)', 'bf16x6': 'f32 (3x3 convs: bf16x6 split, f32 accumulate)',
+                     'bf16x3': 'f32 (3x3 convs: bf16x3 split, f32 accumulate)'}
 ARITH_DTYPE = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convolutions: 2-way fp16 split operands with exact power-of-two range scales, 3 products ~2^-21, fp32 accumulate; all else f32)',
                'bf16x6': 'f32 (3x3 convolutions: 3-way bf16 split operands, 6 products >= 2^-24, fp32 accumulate; all else f32)',
                'bf16x3': 'f32 storage, 3x3 convolutions bf16x3 (2-way split operands, 3 products, ~2^-17 per product, fp32 accumulate)'}
@@ -253,10 +324,13 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-roofline-extra', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the batch-1 eager leg (gen_images.py loop shape)')
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
     ap.add_argument('--conv-arith', default=HEADLINE_ARITH, choices=['default', 'fp32', 'bf16x6', 'f16x3', 'bf16x3'],
-                    help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h).  The library default is fp32; the split '
-                         'arithmetics are an explicit opt-in of callers that own the GPU while the convolutions run, which the bench does')
+                    help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h).  "default" = the library default (fp32), which is what '
+                         'the headline is measured with.  A split arithmetic is an opt-in for callers whose convolutions own the GPU while they run '
+                         '(DESIGN.md 4.2): true for N = 1 here; for N > 1 the asynchronous RCCL gather would run beside them, so the bench then '
+                         'falls back to the blocking gather')
     ap.add_argument('--no-arith-sweep', action='store_true', help='skip the short runs with the other conv arithmetics (N = 1 only)')
     ap.add_argument('--blocking-gather', action='store_true', help='N > 1: synchronous gather on the compute stream in the timed steps')
     ap.add_argument('--dry-run-cpu', action='store_true',
@@ -309,6 +383,11 @@ def main():
         if args.conv_arith != 'default':
             hip_plugin.conv_arithmetic(args.conv_arith)
     arith = hip_plugin.conv_arithmetic() if hip_plugin else 'fp32'
+    # a split arithmetic is only selected where the convolutions own the GPU while they run.  With N > 1 the asynchronous
+    # gather puts RCCL's kernels on a second stream beside step k + 1's convolutions, so a split arithmetic forces the blocking gather.
+    forced_blocking = False
+    if world > 1 and arith != 'fp32' and not args.blocking_gather:
+        args.blocking_gather = forced_blocking = True
 
     torch.manual_seed(0)  # same random-init weights on every rank
     G = triplane.TriPlaneGenerator(triplane.tiny_spec() if cpu else None).eval().to(device)
@@ -439,30 +518,32 @@ def main():
         order = sorted(block_s)
         med = order[len(order) // 2]
         frames_block = BATCH * world * args.steps
+        r3 = lambda v, nd=3: None if v is None else round(float(v), nd)
+        # `out` is the ONE stdout line (compact); `full` collects everything else for gpurun_out/bench_full.json + stderr
         out = {
-            'metric': f'512x512 RGB+seg frames/s @96 depth samples (whole job; 3x3 convolutions in {arith})', 'value': frames_block / med, 'unit': 'frames/s',
-            'value_fp32_exact': (frames_block / med) if arith == 'fp32' else None,     # filled from the fp32 leg of the arithmetic sweep below
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH_DTYPE[arith], 'data': 'synthetic',
-            'config': {'workload': 'gen_images.py-style: random-init ide3d-ffhq-64-512, G.mapping + G.synthesis (64 neural render -> 512, '
-                                   '96 samples, RGB + 19-class seg) + uint8 frame conversion, batch = 4 seeds per GPU',
-                       'global_batch': BATCH * world, 'parallelism': f'dp{world} (one rank per GPU, RCCL gather of uint8 frames)',
-                       'conv_arithmetic': arith},
-            'timing': {'blocks': len(block_s), 'steps_per_block': args.steps, 'reported': 'median block',
-                       'ms_per_step_min': order[0] / args.steps * 1e3, 'ms_per_step_median': med / args.steps * 1e3,
-                       'ms_per_step_max': order[-1] / args.steps * 1e3, 'frames_per_s_min': frames_block / order[-1],
-                       'frames_per_s_max': frames_block / order[0]},
-            'frames_per_s_per_gpu': frames_block / med / world,
-            'conv_tflops': conv_flops(spec, BATCH) * args.steps / med / 1e12,
-            'native_launches': dict(hip_plugin.CALLS) if hip_plugin else {}, 'hip_graph': graphed is not None,
+            'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': r3(frames_block / med, 2), 'unit': 'frames/s',
+            'value_fp32_exact': r3(frames_block / med, 2) if arith == 'fp32' else None,     # else filled from the fp32 leg of the sweep below
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r3(med / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH_DTYPE_SHORT[arith], 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config 2: random-init ide3d-ffhq-64-512, G.mapping + G.synthesis (64 render -> 512, 96 samples, RGB + 19-class seg) '
+                                   '+ uint8 frames, batch 4 seeds per GPU',
+                       'global_batch': BATCH * world, 'parallelism': f'dp{world}', 'conv_arithmetic': arith,
+                       'conv_arithmetic_is_library_default': bool(args.conv_arith == 'default')},
+            'timing': {'blocks': len(block_s), 'reported': 'median block', 'ms_per_step_min': r3(order[0] / args.steps * 1e3, 4),
+                       'ms_per_step_max': r3(order[-1] / args.steps * 1e3, 4)},
+            'conv_tflops': r3(conv_flops(spec, BATCH) * args.steps / med / 1e12, 1),
+            'hip_graph': graphed is not None,
         }
+        full = {'dtype_long': ARITH_DTYPE[arith], 'native_launches': dict(hip_plugin.CALLS) if hip_plugin else {},
+                'timing_blocks_s': block_s, 'frames_per_s_per_gpu': frames_block / med / world}
         if dist:
             out['rccl_ranks'] = world
-            out['frames_per_s_by_rank'] = per_rank
-            out['gather_ms'] = gather_ms
-            out['gather_overlap'] = {'mode': 'async, double-buffered (gather of step k on the communication stream while step k + 1 renders)',
-                                     'ms_per_step_overlapped': med / args.steps * 1e3, 'ms_per_step_blocking_gather': blocking_ms,
-                                     'gather_ms_alone': gather_ms}
+            out['frames_per_s_by_rank'] = [r3(v, 1) for v in per_rank]
+            out['gather_ms'] = r3(gather_ms)
+            out['gather_overlap'] = {'mode': 'blocking (split arithmetic: DESIGN.md 4.2)' if forced_blocking else
+                                             'blocking' if args.blocking_gather else 'async double-buffered',
+                                     'ms_per_step_overlapped': r3(med / args.steps * 1e3, 4), 'ms_per_step_blocking_gather': r3(blocking_ms, 4),
+                                     'gather_ms_alone': r3(gather_ms)}
             out['gather_check'] = gather_check
             out['gather_bytes_per_rank_per_step'] = BATCH * res * 2 * res * 3
         if cpu:
@@ -470,14 +551,19 @@ def main():
             out['data'] = 'synthetic (cpu dry run)'
         pin = None
         if not cpu and not args.no_parity:
-            out['parity'], got = check_parity(render, device)
-            out['parity_ok'] = out['parity'].get('ok')
+            par, got = check_parity(render, device)
+            full['parity'] = par
+            out['parity_ok'] = par.get('ok')
+            out['parity'] = {'max_rel_err': {k: float(f'{v:.3g}') for k, v in (par.get('max_rel_err') or {}).items()}, 'tol_rel': par['tol_rel'],
+                             'vs': 'tests/golden/bench_parity.npz (CPU oracle)'}
             pin = parity_inputs()
+        if not cpu and world == 1 and not args.no_dropin:
+            out['dropin_eager_b1'] = dropin_eager_b1(G, device, palette)
         if not cpu and world == 1 and not args.no_arith_sweep:
             # the same step with the other arithmetics of the 3x3 layers: one captured graph each, the headline's timing protocol, parity against
-            # the same golden frames (nothing else changes: every other kernel is fp32 in all three)
-            sweep = {arith: {'frames_per_s': out['value'], 'ms_per_step': out['ms_per_step'], 'blocks': len(block_s), 'steps_per_block': args.steps,
-                             'reported': 'median block', 'parity_ok': out.get('parity_ok'), 'parity_max_rel_err': (out.get('parity') or {}).get('max_rel_err')}}
+            # the same golden frames (nothing else changes: every other kernel is fp32 in all of them)
+            sweep_full = {arith: {'frames_per_s': frames_block / med, 'ms_per_step': med / args.steps * 1e3, 'blocks': len(block_s), 'steps_per_block': args.steps,
+                                  'reported': 'median block', 'parity_ok': out.get('parity_ok'), 'parity_max_rel_err': (full.get('parity') or {}).get('max_rel_err')}}
             keep = graphed
             for other in ('fp32', 'bf16x6', 'f16x3', 'bf16x3'):
                 if other == arith:
@@ -499,31 +585,54 @@ def main():
                     if not args.no_parity:
                         par = check_parity(render, device)[0]
                         rec['parity_ok'] = par.get('ok'); rec['parity_max_rel_err'] = par.get('max_rel_err')
-                    sweep[other] = rec
+                    sweep_full[other] = rec
                 finally:
                     graphed = keep
                     hip_plugin.conv_arithmetic(args.conv_arith)
-            out['by_conv_arithmetic'] = sweep
-            out['value_fp32_exact'] = sweep['fp32']['frames_per_s']       # exact-fp32 products (v_mfma_f32_32x32x2_f32) in every convolution
-            out['value_fp32_exact_parity_ok'] = sweep['fp32'].get('parity_ok')
+            full['by_conv_arithmetic'] = sweep_full
+            out['by_conv_arithmetic'] = {k: {'frames_per_s': r3(v['frames_per_s'], 1), 'parity_ok': v.get('parity_ok')} for k, v in sweep_full.items()}
+            out['value_fp32_exact'] = r3(sweep_full['fp32']['frames_per_s'], 2)      # exact-fp32 products (v_mfma_f32_32x32x2_f32) in every convolution
         if not cpu and not args.no_roofline:
-            out['roofline'] = bench_gather(device)
+            rf = bench_gather(device)
+            full['roofline'] = rf
+            out['roofline'] = {'kernel': rf['kernel'], 'bound': 'hbm', 'achieved': r3(rf['achieved'], 1), 'peak': rf['peak'], 'unit': 'GB/s',
+                               'frac': r3(rf['frac'], 4), 'traffic': rf['traffic'], 'traffic_measured_in_this_run': False,
+                               'bytes_per_launch': rf['bytes_per_launch'], 'avg_launch_us': r3(rf['avg_launch_us'], 2), 'timed_launches': rf['timed_launches']}
         if not cpu and world == 1 and not args.no_roofline_extra:
             try:
                 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
                 import kernel_rooflines
-                out['roofline_extra'] = kernel_rooflines.measure_all(device, iters=10)
+                extra = kernel_rooflines.measure_all(device, iters=10)
+                full['roofline_extra'] = extra
+                rows = [r for r in (extra.get('rows') if isinstance(extra, dict) else extra) or [] if isinstance(r, dict) and r.get('frac') is not None]
+                rows.sort(key=lambda r: r['frac'])
+                out['roofline_worst'] = [{'kernel': str(r.get('name', r.get('kernel', '?')))[:60], 'bound': r.get('bound'), 'frac': r3(r['frac'], 3),
+                                          'us': r3(r.get('us', r.get('avg_us')), 1)} for r in rows[:5]]
+                out['roofline_rows'] = len(rows)
             except Exception as e:
-                out['roofline_extra'] = {'error': f'{type(e).__name__}: {e}'}
+                out['roofline_worst'] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not cpu and world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], live = cpu_baseline(parity_inputs=pin)
+            cb, live = cpu_baseline(parity_inputs=pin)
+            full['cpu_baseline'] = cb
+            out['cpu_baseline'] = {k: (r3(cb[k]) if k == 'value' else cb[k]) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
             if live is not None and pin is not None:
                 img, seg = got
                 e_img = float((img[:1] - live['image']).abs().max()) / float(live['image'].abs().max())
                 e_seg = float((seg[:1] - live['image_seg']).abs().max()) / float(live['image_seg'].abs().max())
-                out['parity_live'] = {'what': 'image 0 of the parity step vs the oracle frame computed in the cpu_baseline leg of this run',
-                                      'max_rel_err': {'img': e_img, 'seg': e_seg}, 'tol_rel': 2e-3, 'ok': bool(max(e_img, e_seg) <= 2e-3)}
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+                out['parity_live'] = {'vs': 'oracle frame computed in this run (image 0, full frame)', 'max_rel_err': {'img': float(f'{e_img:.3g}'), 'seg': float(f'{e_seg:.3g}')},
+                                      'tol_rel': PARITY_TOL, 'ok': bool(max(e_img, e_seg) <= PARITY_TOL)}
+        line = compact_line(out)
+        full.update(line=json.loads(line))
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'bench_full.json'), 'w') as f:
+                json.dump(full, f, indent=1, default=str)
+            out_path = 'gpurun_out/bench_full.json'
+        except OSError:
+            out_path = None
+        if not cpu:
+            sys.stderr.write('[bench.py] full record' + (f' ({out_path})' if out_path else '') + ':\n' + json.dumps(full, indent=1, default=str) + '\n')
+        os.write(json_fd, (line + '\n').encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -58,3 +58,58 @@ def test_single_process_dry_run():
     assert res.returncode == 0
     rec = _one_json_line(res.stdout)
     assert rec['n_gpus'] == 1 and 'rccl_ranks' not in rec and rec['timing']['blocks'] == 3
+
+
+def _strict(line):
+    """json.loads that rejects NaN / Infinity / -Infinity (what a strict driver-side parser does)."""
+    def bad(tok):
+        raise ValueError(f'non-standard JSON constant {tok}')
+    return json.loads(line, parse_constant=bad)
+
+
+def test_dry_run_line_is_compact_and_strict_json():
+    """round 3's 20 KB line was not parsed by the driver.  The line is < 4096 bytes, ASCII, one line, strict JSON."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + ARGS, stdout=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0
+    raw = res.stdout
+    assert raw.endswith(b'\n') and raw.count(b'\n') == 1
+    assert len(raw) < 4096, len(raw)
+    raw.decode('ascii')
+    rec = _strict(raw.decode())
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in rec, k
+    assert rec['config']['conv_arithmetic'] == 'fp32' and rec['config']['conv_arithmetic_is_library_default'] is True
+    assert 'workload' in rec['config'] and 'model' not in rec['config']
+
+
+def test_compact_line_of_a_full_size_gpu_record():
+    """The N = 1 GPU line carries every optional object; build one with worst-case field widths and check the limit, the strictness
+    (NaN -> null) and the drop order when it would not fit."""
+    sys.path.insert(0, ROOT)
+    import bench
+    big = 123456.789012
+    out = {
+        'metric': '512x512 RGB+seg frames/s @96 depth samples (whole job)', 'value': big, 'unit': 'frames/s', 'value_fp32_exact': big,
+        'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': big, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': bench.ARITH_DTYPE_SHORT['bf16x6'], 'data': 'synthetic',
+        'config': {'workload': 'w' * 180, 'global_batch': 4, 'parallelism': 'dp1', 'conv_arithmetic': 'bf16x6', 'conv_arithmetic_is_library_default': False},
+        'timing': {'blocks': 5, 'reported': 'median block', 'ms_per_step_min': big, 'ms_per_step_max': big},
+        'conv_tflops': big, 'hip_graph': True, 'parity_ok': True,
+        'parity': {'max_rel_err': {'img': 2.34e-06, 'seg': 2.84e-06}, 'tol_rel': 2e-05, 'vs': 'tests/golden/bench_parity.npz (CPU oracle)'},
+        'dropin_eager_b1': {'frames_per_s': big, 'ms_per_image': big, 'images': 24, 'what': 'x' * 90},
+        'by_conv_arithmetic': {k: {'frames_per_s': big, 'parity_ok': True} for k in ('fp32', 'bf16x6', 'f16x3', 'bf16x3')},
+        'roofline': {'kernel': 'triplane_sample_tile_pc_kernel', 'bound': 'hbm', 'achieved': big, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.5591,
+                     'traffic': 258900000, 'traffic_measured_in_this_run': False, 'bytes_per_launch': 320864256, 'avg_launch_us': 71.83, 'timed_launches': 100},
+        'roofline_worst': [{'kernel': 'k' * 60, 'bound': 'split:f16x3', 'frac': 0.123, 'us': big} for _ in range(5)], 'roofline_rows': 55,
+        'cpu_baseline': {'value': 1.001, 'unit': 'frames/s', 'cores': 16, 'kind': 'port', 'sample': 's' * 160},
+        'parity_live': {'vs': 'v' * 60, 'max_rel_err': {'img': float('nan'), 'seg': 3.5e-06}, 'tol_rel': 2e-05, 'ok': True},
+    }
+    line = bench.compact_line(out)
+    assert len(line) < 4096 and '\n' not in line
+    rec = _strict(line)
+    assert rec['parity_live']['max_rel_err']['img'] is None          # NaN never reaches the line
+    assert 'dropped_for_size' not in rec and rec['roofline']['frac'] == 0.5591 and rec['cpu_baseline']['kind'] == 'port'
+    # a record that cannot fit loses optional objects only, never the contract keys / roofline / cpu_baseline
+    out['roofline_worst'] = [{'kernel': 'k' * 60, 'frac': 0.1} for _ in range(80)]
+    rec = _strict(bench.compact_line(out))
+    assert 'roofline_worst' in rec['dropped_for_size'] and 'roofline' in rec and 'cpu_baseline' in rec and rec['value'] == big
