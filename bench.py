@@ -402,7 +402,7 @@ def main():
     # asked for with --graph 0: a silently slower eager number must never stand in for the graph's.
     graphed = None
     if args.graph and not cpu:
-        graphed = triplane.GraphedRenderer(G, BATCH, device)
+        graphed = triplane.GraphedRenderer(G, BATCH, device, static_labels=True)      # cond / cams are fixed device tensors here
 
     def render(z, c_cond, c_cam, jitter=None):
         """The benchmarked callable: new latents (and fresh stratified jitter unless given) -> (img, seg)."""
@@ -570,7 +570,7 @@ def main():
                     continue
                 hip_plugin.conv_arithmetic(other)
                 try:
-                    graphed = triplane.GraphedRenderer(G, BATCH, device) if keep is not None else None
+                    graphed = triplane.GraphedRenderer(G, BATCH, device, static_labels=True) if keep is not None else None
                     for i in range(args.warmup):
                         step(done + i)
                     ts = []

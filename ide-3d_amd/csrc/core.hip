@@ -16,5 +16,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace ide3d
 
 extern "C" const char* ide3d_last_error(void) { return ide3d::g_err; }
-extern "C" int ide3d_abi_version(void) { return 4; }
+extern "C" int ide3d_abi_version(void) { return 5; }
 extern "C" const char* ide3d_build_arch(void) { return "gfx950"; }

@@ -16,6 +16,7 @@
 // grid-wide barrier (monotonic atomic counter; all MAP_WGS = 64 workgroups must be co-resident: checked against the occupancy query
 // on the host, and the spin is bounded).
 #include "common.h"
+#include <atomic>
 
 namespace ide3d {
 namespace {
@@ -188,16 +189,25 @@ extern "C" int ide3d_mapping_workspace_bytes(void) {
 
 // 1 if MAP_WGS workgroups of the mapping kernel are co-resident on the current device with a 2x margin (the occupancy API can be one
 // block per CU high on gfx950 — MI355X_MICROARCH.md "Residency and cooperative launch" — and other kernels may hold part of the chip).
+// Cached PER DEVICE (the answer belongs to the device that is current when the question is asked: a CU-masked or different GPU of the
+// same host must not inherit another device's answer).
 static bool mapping_resident() {
-    static const int ok = [] {
-        int dev = 0, per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ide3d::mapping_kernel, 256, 0) != hipSuccess) return 0;
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cache[MAX_DEV];                               // 0 unknown, 1 no, 2 yes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const bool cached = dev >= 0 && dev < MAX_DEV;
+    if (cached) { const int c = cache[dev].load(std::memory_order_relaxed); if (c) return c == 2; }
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    bool ok = false;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ide3d::mapping_kernel, 256, 0) == hipSuccess) {
         if (per_cu > 1) per_cu -= 1;                                       // the API's possible overcount
-        return ((int64_t)per_cu * prop.multiProcessorCount >= 2 * ide3d::MAP_WGS) ? 1 : 0;
-    }();
-    return ok != 0;
+        ok = (int64_t)per_cu * prop.multiProcessorCount >= 2 * ide3d::MAP_WGS;
+    }
+    if (cached) cache[dev].store(ok ? 2 : 1, std::memory_order_relaxed);
+    return ok;
 }
 extern "C" int ide3d_mapping_supported(void) { return mapping_resident() ? 1 : 0; }
 

@@ -225,7 +225,10 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
     bool staged = false;
     if constexpr (sizeof(T) == 4 && (LH * (LW / 4) + 255) / 256 <= 16) {
         const int64_t pitch = p.x_stride[2];
-        if ((pitch & 3) == 0 && pitch >= 4 && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)) {
+        // 16-byte staging reads whole aligned quads of a row, i.e. up to round_up(in_w, 4) - 1: only when the caller promised that much of
+        // every row is readable (x_row_floats: padded rows) or in_w is a multiple of 4 — the last row of the last plane may end the storage
+        const int w4 = (p.in_w + 3) & ~3;
+        if ((pitch & 3) == 0 && pitch >= w4 && w4 <= max(p.in_w, p.x_row_floats) && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)) {
             const int x_al = in_x0 & ~3;                          // floor to the 16-byte grid (two's complement: also for negative origins)
             xoff = in_x0 - x_al;
             constexpr int NV = LW / 4, NLD4 = (LH * NV + 255) / 256;
@@ -237,7 +240,7 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
                 const int idx = (int)threadIdx.x + k * 256;
                 const int ly = idx / NV, lv = idx - ly * NV;
                 const int gy = in_y0 + ly, gx = x_al + 4 * lv;
-                const int cy_ = min(max(gy, 0), p.in_h - 1), cxv = min(max(gx, 0), (int)pitch - 4);
+                const int cy_ = min(max(gy, 0), p.in_h - 1), cxv = min(max(gx, 0), w4 - 4);
                 v4[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xp) + (int64_t)cy_ * pitch + cxv);
                 const bool rowok = (gy == cy_) && idx < LH * NV;
 #pragma unroll

@@ -20,7 +20,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 4
+_ABI_VERSION = 5
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -52,8 +52,18 @@ class _UpfirdnParams(ctypes.Structure):
         ('f_stride', ctypes.c_int64 * 2),
         ('up_x', ctypes.c_int32), ('up_y', ctypes.c_int32), ('down_x', ctypes.c_int32), ('down_y', ctypes.c_int32),
         ('pad_x0', ctypes.c_int32), ('pad_y0', ctypes.c_int32),
-        ('flip', ctypes.c_int32), ('gain', ctypes.c_float),
+        ('flip', ctypes.c_int32), ('gain', ctypes.c_float), ('x_row_floats', ctypes.c_int32),
     ]
+
+
+def _row_floats_readable(x):
+    """Elements readable from the start of the row of `x` that starts last in its storage (every other row has at least as many): what
+    `ide3d_upfirdn2d_params.x_row_floats` promises.  0 (no promise) for anything but positive-stride rank-4 tensors."""
+    if x.ndim != 4 or any(st <= 0 for st in x.stride()):
+        return 0
+    last_row = x.storage_offset() + sum((x.shape[i] - 1) * x.stride(i) for i in range(3))
+    total = x.untyped_storage().nbytes() // x.element_size()
+    return int(max(0, min(total - last_row, 2 ** 31 - 1)))
 
 
 class _UpfirdnEpilogue(ctypes.Structure):
@@ -409,6 +419,7 @@ class Upfirdn2dPlugin:
         p.up_x, p.up_y, p.down_x, p.down_y = upx, upy, downx, downy
         p.pad_x0, p.pad_y0 = padx0, pady0
         p.flip, p.gain = int(bool(flip)), float(gain)
+        p.x_row_floats = _row_floats_readable(x)
         plain = add is None and noise is None and act is None and y_amax is None
         with torch.cuda.device(x.device):
             if plain:
@@ -1020,11 +1031,14 @@ class MappingPlugin:
     _ws = {}          # (device index, launch domain) -> workspace tensor (per-layer activations + barrier counter); see workspace_scope
 
     @staticmethod
-    def supports(n, z_dim, embed, widths):
+    def supports(n, z_dim, embed, widths, device=None):
+        """`device`: the device the launch will run on (the residency answer is per device; None = the current one)."""
         k0 = z_dim + embed
-        return (1 <= n <= MappingPlugin.MAX_N and 0 < k0 <= MappingPlugin.MAX_WIDTH and k0 % 4 == 0 and 1 <= len(widths) <= MappingPlugin.MAX_LAYERS
-                and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths)
-                and bool(load().ide3d_mapping_supported()))      # the kernel's grid barrier needs its 64 workgroups co-resident
+        if not (1 <= n <= MappingPlugin.MAX_N and 0 < k0 <= MappingPlugin.MAX_WIDTH and k0 % 4 == 0 and 1 <= len(widths) <= MappingPlugin.MAX_LAYERS
+                and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths)):
+            return False
+        with torch.cuda.device(device):                              # None: no-op guard
+            return bool(load().ide3d_mapping_supported())            # the kernel's grid barrier needs its 64 workgroups co-resident
 
     @staticmethod
     def mapping(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff):
@@ -1034,7 +1048,7 @@ class MappingPlugin:
         _require(all(f32c(t) for t in (z, c, embed_w, embed_b, w_avg, *fc_ws, *fc_bs)), 'mapping: contiguous float32 tensors on one CUDA device required')
         n, z_dim = z.shape
         embed = 0 if embed_w is None else embed_w.shape[0]
-        _require(MappingPlugin.supports(n, z_dim, embed, [w.shape[0] for w in fc_ws]), 'mapping: unsupported shape')
+        _require(MappingPlugin.supports(n, z_dim, embed, [w.shape[0] for w in fc_ws], device=dev), 'mapping: unsupported shape')
         # the kernel indexes c as [n, c_dim] and w_avg as [w_dim]: a smaller conditioning batch (torch.cat would raise in the
         # reference, networks.py:302) or a short w_avg must not become an out-of-bounds read
         _require((embed_w is None) or (c is not None and embed_w.ndim == 2 and tuple(c.shape) == (n, embed_w.shape[1])),

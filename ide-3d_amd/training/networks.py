@@ -210,9 +210,10 @@ def _styles_and_dcoefs(affine, w, weight, demodulate):
 # ---- f16x3 arithmetic: the producers' max |y| travels with the activation -------------------------------------------------------
 # The fp16-split convolutions (hip_plugin.conv_arithmetic('f16x3')) scale their input patch by a power of two derived from a bound
 # on |x| per image.  Every fused producer on the render path (convolution epilogue, FIR epilogue) can record max |y| per image for
-# free while it stores y (`y_amax`, one atomic per wave and tile); it rides on the tensor object as `_ide3d_amax` and the consuming
-# convolution picks it up.  A tensor without it (an external caller's input, a tensor somebody modified or converted since) simply
-# makes that launch run in bf16x6.
+# free while it stores y (`y_amax`, one atomic per workgroup); it rides on the tensor object as `_ide3d_amax` = (slots, the tensor's
+# `_version`, its data pointer) and the consuming convolution picks it up only while all three still match (`_amax_of`).  A tensor without
+# it (an external caller's input), one that was converted (another object) or modified in place since (another version) simply makes that
+# launch run in bf16x6.
 def _amax_wanted(x):
     if not (x.is_cuda and x.dtype == torch.float32) or torch.is_grad_enabled():
         return None
@@ -248,12 +249,21 @@ class amax_arena:
 
 
 def _amax_of(x):
-    return getattr(x, '_ide3d_amax', None)
+    """The producer's max |x| slots if `x` is still the tensor the producer returned: same object, same storage address and same
+    version counter.  An in-place edit since (`x.mul_()`, `x.copy_()`, a forward hook) bumps `_version`, so a stale under-bound - which
+    would overflow the fp16 pieces silently - is never handed on; the consuming launch then runs in bf16x6."""
+    rec = getattr(x, '_ide3d_amax', None)
+    if rec is None:
+        return None
+    amax, version, ptr = rec
+    if x._version != version or x.data_ptr() != ptr:
+        return None
+    return amax
 
 
 def _with_amax(y, amax):
     if amax is not None:
-        y._ide3d_amax = amax
+        y._ide3d_amax = (amax, y._version, y.data_ptr())
     return y
 
 
@@ -644,20 +654,26 @@ class MappingNetwork(torch.nn.Module):
                 x = torch.cat([x, y], dim=1) if x is not None else y
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
-        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.training and self.w_avg_beta is not None and not skip_w_avg_update:
+            self._track_w_avg(x)
         if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            x = x[:, None, :].repeat(1, self.num_ws, 1)                      # one copy of w per synthesis layer
+        return self._truncate(x, truncation_psi, truncation_cutoff)
+
+    def _track_w_avg(self, w):
+        """Training only (reference networks.py:308-311): w_avg <- beta * w_avg + (1 - beta) * batch mean of w."""
+        batch_mean = w.detach().mean(dim=0)
+        self.w_avg.copy_(torch.lerp(batch_mean, self.w_avg, self.w_avg_beta))
+
+    def _truncate(self, ws, psi, cutoff):
+        """Truncation trick (reference networks.py:318-324): pull w towards w_avg by 1 - psi, on the first `cutoff` layers only when given."""
+        if psi == 1:
+            return ws
+        assert self.w_avg_beta is not None, 'truncation needs the tracked w_avg'
+        if cutoff is None or self.num_ws is None:
+            return torch.lerp(self.w_avg, ws, psi)
+        ws[:, :cutoff] = torch.lerp(self.w_avg, ws[:, :cutoff], psi)
+        return ws
 
 
 @persistence.persistent_class

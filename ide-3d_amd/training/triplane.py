@@ -445,11 +445,38 @@ class GraphedRenderer:
     Stratified jitter (the reference draws it on every call, volumetric_rendering.py:113): the captured pass reads a static
     buffer `self.jitter`; a call refills it with fresh U[0,1) draws on the device, or with the caller's draws (parity
     tests, `bench.py`'s parity check).  `ray_jitter=False` captures the pass without jitter.
+
+    `conv_arithmetic=` ('fp32' | 'bf16x6' | 'f16x3' | 'bf16x3'): the arithmetic of the 3x3 convolutions INSIDE this graph (the kernels are
+    chosen while it is captured; the process-wide setting is restored afterwards).  None = whatever `hip_plugin.conv_arithmetic()` is in
+    force.  See that function's docstring for when a split arithmetic may be selected.
+
+    `static_labels=True`: a label tensor (c_cond / c_cam) that is the same object at the same `_version` as in the previous call is not
+    copied again.  Opt-in, because `_version` does not see every write (`.data`, numpy views of a CPU tensor, custom kernels): with the
+    default (False) every call copies its labels.
+
+    `z` may be a pinned host tensor; it is copied asynchronously into the static buffer.  The caller must not refill that host buffer
+    before the copy has run: `self.z_copied` is an event recorded right after it (`run.z_copied.synchronize()`), or pass a fresh tensor
+    per call as `bench.py` does.
     """
 
-    def __init__(self, G, batch, device, truncation_psi=1.0, noise_mode='const', warmup=3, ray_jitter=None):
+    def __init__(self, G, batch, device, truncation_psi=1.0, noise_mode='const', warmup=3, ray_jitter=None, conv_arithmetic=None,
+                 static_labels=False):
         self.G = G
         self.psi, self.noise_mode = truncation_psi, noise_mode
+        self.static_labels = bool(static_labels)
+        self.z_copied = torch.cuda.Event() if torch.device(device).type == 'cuda' else None
+        restore = None
+        if conv_arithmetic is not None:
+            from torch_utils import hip_plugin
+            restore = hip_plugin.conv_arithmetic()
+            hip_plugin.conv_arithmetic(conv_arithmetic)
+        try:
+            self._capture(G, batch, device, warmup, ray_jitter)
+        finally:
+            if restore is not None:
+                hip_plugin.conv_arithmetic(restore)
+
+    def _capture(self, G, batch, device, warmup, ray_jitter):
         self.z = torch.zeros([batch, G.z_dim], dtype=torch.float32, device=device)
         self.c_cond = conditioning_label(device).repeat(batch, 1)
         self.c_cam = conditioning_label(device).repeat(batch, 1)
@@ -494,6 +521,8 @@ class GraphedRenderer:
     def _unchanged(self, name, t):
         """True when `t` is the very tensor object, at the same version, that was copied into the static buffer `name` last time (the
         object is kept referenced: a freed tensor's id and address can come back with different contents)."""
+        if not self.static_labels:
+            return False
         last = getattr(self, '_last_' + name, None)
         if last is not None and last[0] is t and last[1] == t._version:
             return True
@@ -502,8 +531,10 @@ class GraphedRenderer:
 
     def __call__(self, z, c_cond=None, c_cam=None, jitter=None):
         # every launch in front of the replay is a few microseconds of GPU timeline: z may be a (pinned) host tensor — one copy straight
-        # into the static buffer, dtype conversion included — and labels that are the tensors of the previous call are not copied again
+        # into the static buffer, dtype conversion included — and (static_labels=True) labels that are the tensors of the previous call are not copied again
         self.z.copy_(z, non_blocking=True)
+        if self.z_copied is not None:
+            self.z_copied.record()
         if c_cond is not None and not self._unchanged('c_cond', c_cond):
             self.c_cond.copy_(c_cond)
         if c_cam is not None and not self._unchanged('c_cam', c_cam):

@@ -79,6 +79,10 @@ typedef struct ide3d_upfirdn2d_params {
     int32_t pad_x0, pad_y0;    /* leading pads (trailing pads are implied by out size) */
     int32_t flip;              /* 1 = correlation (flip_filter=True)                  */
     float   gain;
+    int32_t x_row_floats;      /* ABI 5.  The caller's promise: this many elements may be READ from the start of EVERY row of x (padded row
+                                  storage, e.g. the `y_pitch` output of ide3d_modconv2d mode 2).  0 = no promise beyond in_w.  The tile kernels
+                                  stage rows with 16-byte loads only when round_up(in_w, 4) <= max(in_w, x_row_floats), and never touch an
+                                  element at or beyond round_up(in_w, 4) of a row (values past in_w are discarded). */
 } ide3d_upfirdn2d_params;
 
 int ide3d_upfirdn2d(const ide3d_upfirdn2d_params* p, void* stream);

@@ -9,8 +9,8 @@
             vs the oracle on a strided subset;
   plus the fall-back of the renderer for decoder shapes the fused kernel is not compiled for.
 
-Tolerances (fp32 everywhere): tri-planes 1e-3, raw / final images and seg logits 2e-3 of the tensor's scale (hundreds of fp32
-convolutions with a different summation order); uint8 frames within 1 LSB except < 0.5 % of pixels, seg argmax flips < 0.5 %.
+Tolerances: config 2 (all fp32-grade arithmetics): tri-planes, final images and seg logits 2e-5 of the tensor's scale, raw 64x64 image 1e-4
+(measured values: gpurun_out/parity_measured.json); configs 3-5 as stated in the tests; uint8 frames within 1 LSB except < 0.5 % of pixels, seg argmax flips < 0.5 %.
 `pytest -m gpu`.
 """
 
@@ -63,47 +63,150 @@ def bench_generator(gpu_device):
     return G.to(gpu_device), sd
 
 
-def test_config2_batch4_graph_replay_vs_oracle(bench_generator, gpu_device, oracle_threads):
+MEASURED = {}          # max relative errors observed in this session (written to gpurun_out/parity_measured.json by the last test of the file)
+
+
+def _rel_m(actual, expected, tol, what, key=None):
+    a = actual.detach().cpu().double(); e = torch.as_tensor(expected).detach().cpu().double()
+    assert a.shape == e.shape, f'{what}: shape {tuple(a.shape)} != {tuple(e.shape)}'
+    scale = float(e.abs().max()) + 1e-12
+    err = float((a - e).abs().max())
+    if key is not None:
+        MEASURED[key] = max(MEASURED.get(key, 0.0), err / scale)
+    assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol} * scale {scale:.3e} (rel {err / scale:.2e})'
+
+
+def _config2_inputs():
     from training import triplane
-    from training import distributed_render as dr
-    G, sd = bench_generator
     B = 4
     z = torch.from_numpy(np.stack([np.random.RandomState(s).randn(512) for s in range(B)]))
     cams = torch.cat([triplane.camera_label(y) for y in BENCH_YAWS])
     cond = triplane.conditioning_label().repeat(B, 1)
     jit = torch.rand(B, 4096, 96, generator=torch.Generator().manual_seed(11))
+    return B, z, cams, cond, jit
 
-    run = triplane.GraphedRenderer(G, B, gpu_device)
-    # a replay with other inputs first: the compared replay must not depend on what the capture / previous call left behind
-    run(torch.randn(B, 512, device=gpu_device), cond.to(gpu_device), cams.flip(0).to(gpu_device))
-    img_g, seg_g = run(z.to(gpu_device), cond.to(gpu_device), cams.to(gpu_device), jitter=jit.to(gpu_device))
-    img_g, seg_g = img_g.clone(), seg_g.clone()
-    assert img_g.shape == (B, 3, 512, 512) and seg_g.shape == (B, 19, 512, 512)
 
-    before = _calls('render_rays')
-    with torch.no_grad():
-        ws = G.mapping(z.to(gpu_device).float(), cond.to(gpu_device))
-        out = G.synthesis(ws, c=cams.to(gpu_device), noise_mode='const', ray_jitter=jit.to(gpu_device), return_dict=True)
-    assert _calls('render_rays') == before + 1, 'the fused HIP ray-marcher must have run'
-    assert torch.equal(img_g, out['image']) and torch.equal(seg_g, out['image_seg']), 'hipGraph replay != eager launches at full size'
-
+@pytest.fixture(scope='module')
+def config2_oracle(bench_generator, oracle_threads):
+    """The CPU oracle's outputs for the four images bench.py's parity step renders (computed once for all arithmetics)."""
+    _G, sd = bench_generator
+    B, z, cams, cond, jit = _config2_inputs()
     osp = ospec.Spec()
-    frames_gpu = dr.frames_u8(img_g, seg_g, dr.palette_tensor(19, gpu_device)).cpu().numpy()
+    refs = []
     for i in range(B):          # one oracle image at a time (memory)
         ws_o = ogen.mapping(sd, osp, z[i:i + 1], cond[i:i + 1], ops=fast_ops)
-        _rel(ws[i:i + 1], ws_o, 1e-4, f'ws[{i}]')
         ref = ogen.synthesis(sd, osp, ws_o, cams[i:i + 1], jitter=jit[i:i + 1], ops=fast_ops)
-        _rel(out['planes'][0][i:i + 1], ref['planes'][0], 1e-3, f'texture tri-plane [{i}]')
-        _rel(out['planes'][1][i:i + 1], ref['planes'][1], 1e-3, f'semantic tri-plane [{i}]')
-        _rel(out['image_raw'][i:i + 1], ref['image_raw'], 2e-3, f'raw 64x64 image [{i}]')
-        _rel(img_g[i:i + 1], ref['image'], 2e-3, f'image 512 [{i}]')
-        _rel(seg_g[i:i + 1], ref['image_seg'], 2e-3, f'seg 512 [{i}]')
-        want = oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0]
+        refs.append(dict(ws=ws_o, planes=[p.clone() for p in ref['planes']], image_raw=ref['image_raw'], image=ref['image'], image_seg=ref['image_seg'],
+                         frame=oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0]))
+    return refs
+
+
+@pytest.mark.parametrize('arith', ['fp32', 'bf16x6', 'f16x3'])
+def test_config2_batch4_graph_replay_vs_oracle(bench_generator, config2_oracle, gpu_device, arith):
+    """BASELINE config 2 exactly as bench.py times it (batch 4, captured hipGraph), FULL frames, in the library-default arithmetic and in
+    both fp32-grade split arithmetics: every image vs the CPU oracle at 2e-5 of the tensor's scale (VERDICT r3 item 6b: measured 3e-6;
+    the round-3 bound was 2e-3), graph replay == eager launches bit for bit, uint8 frames within 1 LSB."""
+    from torch_utils import hip_plugin
+    from training import triplane
+    from training import distributed_render as dr
+    G, _sd = bench_generator
+    B, z, cams, cond, jit = _config2_inputs()
+    try:
+        run = triplane.GraphedRenderer(G, B, gpu_device, conv_arithmetic=arith)
+        assert hip_plugin.conv_arithmetic() == 'fp32', 'GraphedRenderer(conv_arithmetic=) must restore the process setting'
+        # a replay with other inputs first: the compared replay must not depend on what the capture / previous call left behind
+        run(torch.randn(B, 512, device=gpu_device), cond.to(gpu_device), cams.flip(0).to(gpu_device))
+        img_g, seg_g = run(z.to(gpu_device), cond.to(gpu_device), cams.to(gpu_device), jitter=jit.to(gpu_device))
+        img_g, seg_g = img_g.clone(), seg_g.clone()
+        assert img_g.shape == (B, 3, 512, 512) and seg_g.shape == (B, 19, 512, 512)
+
+        hip_plugin.conv_arithmetic(arith)
+        before = _calls('render_rays')
+        with torch.no_grad():
+            ws = G.mapping(z.to(gpu_device).float(), cond.to(gpu_device))
+            out = G.synthesis(ws, c=cams.to(gpu_device), noise_mode='const', ray_jitter=jit.to(gpu_device), return_dict=True)
+        assert _calls('render_rays') == before + 1, 'the fused HIP ray-marcher must have run'
+    finally:
+        hip_plugin.conv_arithmetic('default')
+    assert torch.equal(img_g, out['image']) and torch.equal(seg_g, out['image_seg']), f'{arith}: hipGraph replay != eager launches at full size'
+
+    frames_gpu = dr.frames_u8(img_g, seg_g, dr.palette_tensor(19, gpu_device)).cpu().numpy()
+    for i, ref in enumerate(config2_oracle):
+        _rel_m(ws[i:i + 1], ref['ws'], 2e-5, f'ws[{i}]', f'{arith}/ws')
+        _rel_m(out['planes'][0][i:i + 1], ref['planes'][0], 2e-5, f'{arith}: texture tri-plane [{i}]', f'{arith}/planes_tex')
+        _rel_m(out['planes'][1][i:i + 1], ref['planes'][1], 2e-5, f'{arith}: semantic tri-plane [{i}]', f'{arith}/planes_seg')
+        _rel_m(out['image_raw'][i:i + 1], ref['image_raw'], 1e-4, f'{arith}: raw 64x64 image [{i}]', f'{arith}/image_raw')
+        _rel_m(img_g[i:i + 1], ref['image'], 2e-5, f'{arith}: image 512 [{i}]', f'{arith}/image')
+        _rel_m(seg_g[i:i + 1], ref['image_seg'], 2e-5, f'{arith}: seg 512 [{i}]', f'{arith}/image_seg')
+        want = ref['frame']
         got = frames_gpu[i]
         rgb_off = np.abs(got[:, :512].astype(np.int32) - want[:, :512].astype(np.int32)) > 1
         assert rgb_off.mean() < 5e-3, f'uint8 RGB frame [{i}]: {rgb_off.mean():.4f} of the values differ by more than 1 LSB'
         flips = (got[:, 512:] != want[:, 512:]).any(axis=-1)
         assert flips.mean() < 5e-3, f'seg colour frame [{i}]: {flips.mean():.4f} argmax flips'
+
+
+def test_dropin_batch1_eager_equals_graphed_batch4_row(bench_generator, gpu_device):
+    """What a drop-in caller of gen_images.py:88-114 runs — batch 1, eager launches, library-default arithmetic — against the row of the
+    benchmarked batch-4 graph for the same seed / camera / jitter.  Kernel selection depends on the batch (split-K planning follows the
+    number of workgroups), so the two may differ in summation order: bit equality is reported (MEASURED), closeness at fp32 rounding
+    level (1e-5 of the scale) is required."""
+    from training import triplane
+    G, _sd = bench_generator
+    B, z, cams, cond, jit = _config2_inputs()
+    dev = gpu_device
+    run = triplane.GraphedRenderer(G, B, dev)
+    img4, seg4 = run(z.to(dev), cond.to(dev), cams.to(dev), jitter=jit.to(dev))
+    img4, seg4 = img4.clone(), seg4.clone()
+    equal = True
+    for i in range(B):
+        with torch.no_grad():
+            ws = G.mapping(z[i:i + 1].to(dev).float(), cond[i:i + 1].to(dev))
+            img1, seg1 = G.synthesis(ws, c=cams[i:i + 1].to(dev), noise_mode='const', return_seg=True, ray_jitter=jit[i:i + 1].to(dev))
+        equal = equal and torch.equal(img1, img4[i:i + 1]) and torch.equal(seg1, seg4[i:i + 1])
+        _rel_m(img1, img4[i:i + 1], 1e-5, f'batch-1 eager image [{i}] vs graphed batch-4 row', 'dropin_b1/image')
+        _rel_m(seg1, seg4[i:i + 1], 1e-5, f'batch-1 eager seg [{i}] vs graphed batch-4 row', 'dropin_b1/image_seg')
+    MEASURED['dropin_b1/bit_equal'] = bool(equal)
+
+
+def test_f16x3_frame_with_weight_rows_and_columns_over_many_octaves(bench_generator, gpu_device, oracle_threads):
+    """Frame-level stress of f16x3's block scaling: the full-size generator with every 3x3 convolution's weight ROWS
+    scaled by 2^U(-12, 12) (the demodulation cancels a row scale exactly, so the function is unchanged but the per-row power-of-two scale
+    chosen at pack time and the demodulation coefficients span 24 octaves) and its input COLUMNS by 2^U(-4, 4) (not cancelled: the
+    operands x * s inside one image then span 8+ octaves, what a trained pickle's styles do) — one image vs the CPU oracle on the same
+    weights, in f16x3 and in the fp32 default, same 2e-5 bound."""
+    import copy
+    from torch_utils import hip_plugin
+    from training import triplane
+    G0, _ = bench_generator
+    G = copy.deepcopy(G0)
+    gen = torch.Generator().manual_seed(5)
+    n_scaled = 0
+    with torch.no_grad():
+        for name, prm in G.named_parameters():
+            if name.endswith('.weight') and prm.ndim == 4 and prm.shape[-1] == 3:
+                rows = torch.exp2(torch.randint(-12, 13, [prm.shape[0], 1, 1, 1], generator=gen).float()).to(prm.device)
+                cols = torch.exp2(torch.randint(-4, 5, [1, prm.shape[1], 1, 1], generator=gen).float()).to(prm.device)
+                prm.mul_(rows).mul_(cols)
+                n_scaled += 1
+    assert n_scaled >= 18
+    sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    _B, z, cams, cond, jit = _config2_inputs()
+    osp = ospec.Spec()
+    ws_o = ogen.mapping(sd, osp, z[:1], cond[:1], ops=fast_ops)
+    ref = ogen.synthesis(sd, osp, ws_o, cams[:1], jitter=jit[:1], ops=fast_ops)
+    dev = gpu_device
+    try:
+        for arith in ('fp32', 'f16x3'):
+            hip_plugin.conv_arithmetic(arith)
+            with torch.no_grad():
+                ws = G.mapping(z[:1].to(dev).float(), cond[:1].to(dev))
+                out = G.synthesis(ws, c=cams[:1].to(dev), noise_mode='const', ray_jitter=jit[:1].to(dev), return_dict=True)
+            _rel_m(out['planes'][0], ref['planes'][0], 2e-5, f'{arith}: texture tri-plane, scaled weights', f'scaled_weights/{arith}/planes_tex')
+            _rel_m(out['image'], ref['image'], 2e-5, f'{arith}: image, scaled weights', f'scaled_weights/{arith}/image')
+            _rel_m(out['image_seg'], ref['image_seg'], 2e-5, f'{arith}: seg, scaled weights', f'scaled_weights/{arith}/image_seg')
+    finally:
+        hip_plugin.conv_arithmetic('default')
 
 
 def test_config3_full_size_grid_frame_vs_oracle(bench_generator, gpu_device, oracle_threads):
@@ -262,3 +365,12 @@ def test_bench_parity_fixture_per_conv_arithmetic(bench_generator, gpu_device):
     assert errs['bf16x6'] < 2 * errs['fp32'] + 1e-6, f'bf16x6 is not fp32-grade at frame level: {errs}'
     assert errs['f16x3'] < 2 * errs['fp32'] + 1e-6, f'f16x3 is not fp32-grade at frame level: {errs}'
     assert errs['f16x3'] != errs['bf16x6'], 'f16x3 must actually run (every producer on the render path hands its amax on)'
+
+
+def test_zz_write_measured_parity():
+    """Not a check: stores the max relative errors the tests above measured (gpurun_out/parity_measured.json -> profiles/)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(root, 'gpurun_out', 'parity_measured.json'), 'w') as f:
+        json.dump({k: MEASURED[k] for k in sorted(MEASURED)}, f, indent=1)

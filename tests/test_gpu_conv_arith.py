@@ -438,3 +438,45 @@ def test_foreign_aten_kernels_beside_the_convolutions(gpu_device):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, 'aten_victims.json'), 'w') as f:
         json.dump(record, f, indent=1)
+
+
+def test_amax_is_dropped_when_the_activation_is_edited_in_place(gpu_device):
+    """VERDICT r3 item 6a / ADVICE: the producer's max |y| rides on the tensor object; an in-place edit between producer and consumer
+    (`x.mul_(4)`: a hook, a viewer) must make the consumer IGNORE it (stale under-bound -> fp16 overflow) and run bf16x6 instead.  The
+    guard is (object, `_version`, data pointer).  Result of the consumer: bit-equal to the bf16x6 launch and within 4e-6 of float64."""
+    from torch_utils import hip_plugin
+    from training import networks
+    torch.manual_seed(3)
+    la = networks.SynthesisLayer(64, 64, w_dim=32, resolution=64).to(gpu_device).eval()
+    lb = networks.SynthesisLayer(64, 64, w_dim=32, resolution=64).to(gpu_device).eval()
+    x = torch.randn(2, 64, 64, 64, device=gpu_device)
+    w = torch.randn(2, 32, device=gpu_device)
+    try:
+        hip_plugin.conv_arithmetic('f16x3')
+        with torch.no_grad():
+            y = la(x, w, noise_mode='const')
+            assert networks._amax_of(y) is not None, 'the producer must hand its amax on in f16x3'
+            assert torch.equal(networks._amax_of(y).amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
+            out_clean = lb(y, w, noise_mode='const')                       # consumer in f16x3
+            y2 = y.clone(); y2._ide3d_amax = y._ide3d_amax                 # a copy is another object at another address: also not trusted
+            assert networks._amax_of(y2) is None
+            y.mul_(4)                                                      # amax now under-estimates |y| by 4x
+            assert networks._amax_of(y) is None, 'a stale amax must not reach the consumer'
+            out_edit = lb(y, w, noise_mode='const')
+        hip_plugin.conv_arithmetic('bf16x6')
+        with torch.no_grad():
+            out_b6 = lb(y, w, noise_mode='const')
+    finally:
+        hip_plugin.conv_arithmetic('default')
+    assert torch.equal(out_edit, out_b6), 'without a trusted amax the f16x3 request must run the bf16x6 loop'
+    assert torch.isfinite(out_edit).all()
+    # float64 reference of layer b on the edited input
+    with torch.no_grad():
+        styles = lb.affine(w).double()
+        wt = lb.weight.double()
+        ww = wt[None] * styles[:, None, :, None, None]
+        d = (ww.square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt()
+        conv = torch.nn.functional.conv2d((y.double() * styles[:, :, None, None]).cpu(), wt.cpu(), padding=1).to(gpu_device) * d[:, :, None, None]
+        ref = torch.nn.functional.leaky_relu(conv + (lb.noise_const * lb.noise_strength).double() + lb.bias.double()[None, :, None, None], 0.2) * math.sqrt(2)
+    err = float((out_edit.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 4e-6, err
