@@ -16,8 +16,9 @@ Timing: W untimed warm-up steps, then `--blocks` (default 5) timed blocks of EXA
 are reported next to it: box-to-box and run-to-run spread is a few per cent).
 
 Rank 0 prints ONE COMPACT JSON line (< 4 KB, contract in the task statement; tests/test_bench_launcher_cpu.py checks the size and a
-strict `json.loads`).  `value` is measured with the LIBRARY-DEFAULT convolution arithmetic (exact fp32 products) — what a drop-in caller
-gets; the opt-in split arithmetics are listed next to it in `by_conv_arithmetic`.  Extra objects in the line:
+strict `json.loads`).  `value` is measured with the LIBRARY-DEFAULT convolution arithmetic (bf16x6: every fp32 operand as three bf16
+pieces, six products, fp32 accumulation — as accurate as the fp32 matrix instruction against float64) — what a drop-in caller gets; exact
+fp32 products (`value_fp32_exact`) and the other arithmetics are listed next to it in `by_conv_arithmetic`.  Extra objects in the line:
   roofline         the tri-plane gather kernel (the kernel BASELINE's metric names): algorithmic bytes / HIP-event time
   roofline_worst   the five hand-written kernels furthest below their roofline at their config-2 shapes (scripts/kernel_rooflines.py)
   cpu_baseline     the CPU oracle ("port" of the reference's PyTorch CPU path) timed on the host cores, rank 0, N = 1 only
@@ -52,7 +53,7 @@ BATCH = 4                    # seeds per rank per step (BASELINE config 2)
 PROFILE_ROUND = 'round4'
 YAWS = (-0.5, 0.0, 0.5, 0.25)
 PARITY_JITTER_SEED = 11      # = oracle/make_bench_parity.py
-HEADLINE_ARITH = 'default'   # the library default (`ide3d_get_conv_arithmetic()` of a fresh process: exact fp32 products) - what a drop-in caller runs
+HEADLINE_ARITH = 'default'   # the library default (`ide3d_get_conv_arithmetic()` of a fresh process: bf16x6, fp32-grade) - what a drop-in caller runs
 PARITY_TOL = 2e-5            # of the image / logit scale; measured 2-4e-6 in every arithmetic but bf16x3 (1.4e-5)
 LINE_LIMIT = 4096            # bytes of the ONE stdout line (round 3's 20 KB line was not parsed by the driver)
 
@@ -305,7 +306,7 @@ def dropin_eager_b1(G, device, palette, images=24, warm=4):
             'what': 'gen_images.py loop shape: batch 1, eager launches, library-default arithmetic'}
 
 
-ARITH_DTYPE_SHORT = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convs: f16x3 split, f32 accumulate)', 'bf16x6': 'f32 (3x3 convs: bf16x6 split, f32 accumulate)',
+ARITH_DTYPE_SHORT = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convs: f16x3 split, f32 accumulate)', 'bf16x6': 'f32 (3x3 convs + MLPs: fp32 operands as 3 bf16 pieces, 6 products, f32 accumulate)',
                      'bf16x3': 'f32 (3x3 convs: bf16x3 split, f32 accumulate)'}
 ARITH_DTYPE = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convolutions: 2-way fp16 split operands with exact power-of-two range scales, 3 products ~2^-21, fp32 accumulate; all else f32)',
                'bf16x6': 'f32 (3x3 convolutions: 3-way bf16 split operands, 6 products >= 2^-24, fp32 accumulate; all else f32)',
@@ -327,10 +328,9 @@ def main():
     ap.add_argument('--no-dropin', action='store_true', help='skip the batch-1 eager leg (gen_images.py loop shape)')
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
     ap.add_argument('--conv-arith', default=HEADLINE_ARITH, choices=['default', 'fp32', 'bf16x6', 'f16x3', 'bf16x3'],
-                    help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h).  "default" = the library default (fp32), which is what '
-                         'the headline is measured with.  A split arithmetic is an opt-in for callers whose convolutions own the GPU while they run '
-                         '(DESIGN.md 4.2): true for N = 1 here; for N > 1 the asynchronous RCCL gather would run beside them, so the bench then '
-                         'falls back to the blocking gather')
+                    help='arithmetic of the shared-weight 3x3 convolutions (include/ide3d_hip.h).  "default" = the library default (bf16x6: fp32-grade '
+                         'split products on the bf16 matrix pipe), which is what the headline is measured with; fp32 = exact fp32 products '
+                         '(reported as value_fp32_exact either way)')
     ap.add_argument('--no-arith-sweep', action='store_true', help='skip the short runs with the other conv arithmetics (N = 1 only)')
     ap.add_argument('--blocking-gather', action='store_true', help='N > 1: synchronous gather on the compute stream in the timed steps')
     ap.add_argument('--dry-run-cpu', action='store_true',
@@ -383,11 +383,7 @@ def main():
         if args.conv_arith != 'default':
             hip_plugin.conv_arithmetic(args.conv_arith)
     arith = hip_plugin.conv_arithmetic() if hip_plugin else 'fp32'
-    # a split arithmetic is only selected where the convolutions own the GPU while they run.  With N > 1 the asynchronous
-    # gather puts RCCL's kernels on a second stream beside step k + 1's convolutions, so a split arithmetic forces the blocking gather.
-    forced_blocking = False
-    if world > 1 and arith != 'fp32' and not args.blocking_gather:
-        args.blocking_gather = forced_blocking = True
+    forced_blocking = False      # (round 3 forced the blocking gather beside split arithmetics; exclusive residency made that unnecessary: DESIGN.md 4.2)
 
     torch.manual_seed(0)  # same random-init weights on every rank
     G = triplane.TriPlaneGenerator(triplane.tiny_spec() if cpu else None).eval().to(device)

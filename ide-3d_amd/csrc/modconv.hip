@@ -956,11 +956,15 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 // (lane = pixel, 8 channels of its k half = 8 coalesced dword loads), splits it into bf16 pieces in registers and multiplies it
 // with the A fragments of all MT row tiles, which the four waves share through LDS (pre-split packed weights [chunk][piece][k half]
 // [row][8], double-buffered LDS-DMA).  The accumulator layout has lane = pixel, so every store instruction writes 128-byte runs.
+// Exclusive residency (see kSpExclusive below): 8 waves = two of this workgroup's waves per SIMD, 256 pixels per workgroup, one workgroup
+// per CU; every wave stays until the barrier behind the K loop.
+constexpr int kHeadWaves = 8;
 template <int PARTS, int MT>
 struct HeadCfg {
     static constexpr int ROWS = MT * 32;
     static constexpr int A_UNITS = PARTS * 2 * ROWS;                  // 16-byte units per 16-channel chunk
-    static constexpr int BN = 128;
+    static constexpr int NWV = kHeadWaves;
+    static constexpr int BN = 32 * NWV;
 };
 __host__ __device__ inline int64_t head_packed_units(int n, int cchunks, int parts, int mt) { return (int64_t)n * cchunks * parts * 2 * mt * 32; }
 
@@ -993,10 +997,12 @@ head_pack_split_kernel(const float* __restrict__ w, int64_t w_batch_stride, int 
 }
 
 template <int PARTS, int MT>
-__global__ void __launch_bounds__(256, 2)        // MT = 6 needs ~170 registers: a third workgroup per CU spills (measured 264 vs 114 us)
+__global__ void __launch_bounds__(64 * kHeadWaves, 2)        // two waves per SIMD, both of this workgroup (<= 256 registers each)
 head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchunks, int tiles_per_image) {
     using K = HeadCfg<PARTS, MT>;
-    constexpr int S_UNITS = (2 * K::A_UNITS > 512) ? 2 * K::A_UNITS : 512;   // >= 8 KB: the epilogue's staging tiles
+    asm volatile("" ::: "v255");                                             // each wave holds half of its SIMD's register file: no foreign wave fits
+    constexpr int S_MIN = K::NWV * 32 * 40 / 4 + 2 * K::ROWS / 4 + 16;       // the epilogue's staging tiles: 32 rows x (32 + 8) floats per wave
+    constexpr int S_UNITS = (2 * K::A_UNITS > S_MIN) ? 2 * K::A_UNITS : S_MIN;
     __shared__ __attribute__((aligned(16))) u32x4 s_a[S_UNITS];              // weights of chunk c and c + 1 (L2-resident, one chunk of look-ahead)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1017,7 +1023,7 @@ head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchu
     constexpr int A_PIECES = K::A_UNITS / 64;
     static_assert(K::A_UNITS % 64 == 0, "whole 1 KB pieces");
     auto fetch_a = [&](int c, int buf) {
-        for (int i = wid; i < A_PIECES; i += 4)
+        for (int i = wid; i < A_PIECES; i += K::NWV)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (int64_t)c * K::A_UNITS + i * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(s_a + buf * K::A_UNITS + i * 64), 16, 0, 0);
     };
@@ -1077,7 +1083,7 @@ head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchu
     pf.h = 1; pf.w_ = hw;
     ConvGeom g{};
     g.oh = 1; g.ow = hw; g.split_k = 1;
-    modconv_finish<MODE_CONV1, 1, 1, K::BN, 4, 1, MT, 1, K::ROWS, S_UNITS * 4>(pf, nullptr, g, acc, reinterpret_cast<float*>(s_a), 0, n0, 0, tile * K::BN, 0, 0, 0, wid, l32);
+    modconv_finish<MODE_CONV1, 1, 1, K::BN, K::NWV, 1, MT, 1, K::ROWS, S_UNITS * 4>(pf, nullptr, g, acc, reinterpret_cast<float*>(s_a), 0, n0, 0, tile * K::BN, 0, 0, 0, wid, l32);
 }
 
 // ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
@@ -1110,16 +1116,17 @@ modconv_kernel(ide3d_modconv_params p, const float* __restrict__ wp, float* __re
 }
 
 
-// Build option (make EXTRA=-DIDE3D_SP_EXCLUSIVE_SIMD): every split-bf16 workgroup claims the whole register file of its SIMDs (512
-// registers for a 4-wave workgroup's wave, 256 for each of the two waves an 8-wave workgroup puts on a SIMD), so that no wave of
-// ANOTHER kernel can sit beside a bf16 MFMA wave.  Measured on MI355X: packed fp32 VALU instructions (v_pk_fma_f32 ...) of a
-// foreign wave return wrong results while a wave on the same SIMD executes v_mfma_f32_32x32x16_bf16; this library contains none
-// (csrc/Makefile), the option protects kernels of other libraries on other streams.  Cost: configurations that otherwise hold two
-// workgroups per CU lose 20-60 %.
-#ifdef IDE3D_SP_EXCLUSIVE_SIMD
-constexpr bool kSpExclusive = true;
-#else
+// EXCLUSIVE RESIDENCY (round 4).  On MI355X a packed-fp32 instruction (v_pk_fma_f32 ...) of ANOTHER kernel's wave that
+// consumes registers a global load has just written returns wrong values while a wave on the SAME SIMD runs a loop of LDS reads + bf16 / fp16
+// MFMAs (scripts/micro/pk_mfma_hazard2.cpp: victims on another SIMD of the same CU are never hit, 0 of 3000 launches against 2980 of 3000).
+// The foreign kernel cannot be fixed from here, so every kernel of this library that contains such a loop makes sure no foreign wave can
+// share its SIMDs while the loop runs: an 8-wave workgroup puts two of its own waves, 256 registers each, on every SIMD (all waves are
+// allocated together and none leaves before the last barrier of the K loop); a 4-wave workgroup's wave claims all 512 registers of its SIMD.
+// `make EXTRA=-DIDE3D_SP_SHARED_SIMD` drops the claims (A/B experiments only: two 4-wave workgroups per CU again).
+#ifdef IDE3D_SP_SHARED_SIMD
 constexpr bool kSpExclusive = false;
+#else
+constexpr bool kSpExclusive = true;
 #endif
 template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV>
 constexpr int sp_waves_per_simd() {
@@ -1130,9 +1137,7 @@ template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV = 4, int F
 __global__ void __launch_bounds__(64 * NWV, (sp_waves_per_simd<MODE, BIG, PH, PARTS, WBUF, NWV>()))
 modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
-#ifdef IDE3D_SP_EXCLUSIVE_SIMD
-    if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255");
-#endif
+    if constexpr (kSpExclusive) { if constexpr (NWV == 8) asm volatile("" ::: "v255"); else asm volatile("" ::: "v255", "a255"); }
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
     modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
@@ -1263,19 +1268,22 @@ static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
 }
 
 // Arithmetic of the big 3x3 layers: 1 = fp32 MFMA (exact fp32 products), 6 = three bf16 pieces per operand / 6 products
-// (fp32-grade), 3 = two pieces / 3 products (~2^-17 relative per product), 16 = two fp16 pieces / 3 products with exact power-of-two
-// range scales (~2^-21; needs x_amax).  Process default: IDE3D_CONV_ARITH, else fp32 — the split arithmetics are opt-in (a foreign
-// kernel's packed-fp32 wave beside an LDS-fed bf16 / fp16 MFMA loop returns wrong results on MI355X: DESIGN.md section 4.2).
+// (fp32-grade: per-product error <= 2^-23 relative, measured as accurate as the fp32 MFMA against float64), 3 = two pieces / 3 products
+// (~2^-17 relative per product), 16 = two fp16 pieces / 3 products with exact power-of-two range scales (~2^-21; needs x_amax).
+// Process default: IDE3D_CONV_ARITH, else bf16x6 (round 4).  Rounds 2-3 kept fp32 as the default because a foreign kernel's packed-fp32
+// wave beside an LDS-fed bf16 / fp16 MFMA loop returns wrong results on MI355X; every such loop of this library now keeps foreign waves
+// off its SIMDs (exclusive residency, `kSpExclusive` above / DESIGN.md section 4.2), so the fp32-grade split arithmetic is the default.
 static int g_conv_arith = 0;
 static int conv_arith_default() {
     if (g_conv_arith) return g_conv_arith;
     static const int env = [] {
         const char* e = getenv("IDE3D_CONV_ARITH");
-        if (!e) return 1;
+        if (!e) return 6;
+        if (!strcmp(e, "fp32") || !strcmp(e, "1")) return 1;
         if (!strcmp(e, "bf16x3") || !strcmp(e, "3")) return 3;
         if (!strcmp(e, "bf16x6") || !strcmp(e, "6")) return 6;
         if (!strcmp(e, "f16x3") || !strcmp(e, "16")) return 16;
-        return 1;
+        return 6;
     }();
     return env;
 }
@@ -1354,6 +1362,21 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         pl.parts = (arith == 3 || arith == 16) ? 2 : 3;
         pl.f16 = (arith == 16) ? 1 : 0;
         static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
+        // Exclusive residency (round 4): one workgroup per CU, so the forms that put TWO of their own waves on a SIMD (8 waves) are chosen
+        // wherever the launch still has >= 2 workgroups per CU to run through; measured per layer, bf16x6 / f16x3 us at batch 4:
+        //   64 -> 64 @512: 16 x 16 px x 64 rows, 8 waves 431 / 343 (8 x 16, 4 waves with the whole SIMD claimed: 537 / 457)
+        //   transposed 256 -> 128 in@128: 8 x 16 positions x 128 rows, 8 waves 250 / 175 (4 x 16, 4 waves: 269 / 207)
+        //   transposed 128 -> 64 in@256: 16 x 16 positions x 64 rows, 8 waves 270 / 211 (8 x 16, 4 waves: 318 / 263)
+        //   transposed 512 -> 256 in@64 (360 workgroups of 8 x 16): stays on 4 x 16, 4 waves 292 / 215 (8 waves: 401 / 325)
+        if (kSpExclusive && !getenv("IDE3D_MODCONV_SP_OLDPLAN")) {
+            if (pl.mode == MODE_CONV3) {
+                if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n >= 2 * kNumCU) pl.tile = 3;
+            } else {
+                const int64_t b8 = (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n, b16 = (int64_t)pl.mblocks * cdiv(p.h + 1, 16) * cdiv(p.w_ + 1, 16) * p.n;
+                if (pl.big == 1) pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
+                else if (b16 >= 2 * kNumCU) pl.tile = 7;
+            }
+        }
         if (pl.mode == MODE_CONV3) {
             if (sp_rows == 8) pl.tile = 0;
             if (sp_rows == 16) pl.tile = 3;
@@ -1423,23 +1446,29 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
 }
 
 
+constexpr int kSpW8Default = kSpExclusive ? 2 : 0;
 template <int MODE, int BIG, int PARTS, int F16 = 0>
 static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
     const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale] behind the packed weights
+    // 8-wave forms (two of this workgroup's waves per SIMD: exclusive residency without giving up the second wave): IDE3D_SP_W8 bit 0 =
+    // 3x3 on 8 x 16 pixels, bit 1 = all-class transposed 3x3 (8 x 16 positions at 128 rows, 16 x 16 at 64 rows)
+    static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
     if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru); }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
-        static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr;
-        if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr && !kSpExclusive;
+        if (w8 & (MODE == MODE_CONV3 ? 1 : 2)) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+        else if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
         else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
-        // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6;
-        // the all-class transposed form keeps 4 waves: 279 vs 268 us); IDE3D_MODCONV_SP_W4 = 4 waves everywhere
-        static const bool eight = getenv("IDE3D_MODCONV_SP_W4") == nullptr && MODE == MODE_CONV3;
+        // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6);
+        // IDE3D_MODCONV_SP_W4 = 4 waves everywhere
+        static const bool no8 = getenv("IDE3D_MODCONV_SP_W4") != nullptr;
+        const bool eight = !no8 && (MODE == MODE_CONV3 || (w8 & 2));
         if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
         else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
@@ -1452,7 +1481,7 @@ static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
     static const bool off = getenv("IDE3D_MODCONV_HEAD_FP32") != nullptr;
     return !off && arith != 1 && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 &&
            (p.cout <= 32 || (p.cout > 160 && p.cout <= 192)) && p.cin >= 32 &&
-           (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 128) >= 2 * ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
+           (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 32 * ide3d::kHeadWaves) >= ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
                                                                               // (512 channels @32^2 / @64^2: 54 us against 16 / 40 us on the fp32 loop)
 }
 
@@ -1507,10 +1536,10 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         IDE3D_CHECK_ARG(p.workspace_bytes >= head_packed_units(p.n, cchunks, parts, mt) * 16, "modconv2d: workspace too small for the packed head weights");
         u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
         const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
-        const int tiles = cdiv(p.h * p.w_, 128);
+        const int tiles = cdiv(p.h * p.w_, 32 * kHeadWaves);
 #define IDE3D_HEAD(P, M) do { \
             hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
-            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(256), 0, st_head, p, wu, cchunks, tiles); } while (0)
+            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * kHeadWaves), 0, st_head, p, wu, cchunks, tiles); } while (0)
         if (parts == 2) { if (mt == 1) IDE3D_HEAD(2, 1); else IDE3D_HEAD(2, 6); }
         else            { if (mt == 1) IDE3D_HEAD(3, 1); else IDE3D_HEAD(3, 6); }
 #undef IDE3D_HEAD

@@ -436,10 +436,20 @@ __device__ __forceinline__ void mlp_branch(const unsigned char* sm, const float 
     else mlp_tile<C, HID>(reinterpret_cast<const float*>(sm), f, out);
 }
 
+// Exclusive residency (modconv.hip `kSpExclusive`): the SPLIT forms of the three kernels below run LDS-fed bf16
+// MFMA loops, beside which a foreign wave's packed-fp32 instructions return wrong values on MI355X.  They are therefore launched as 8-wave
+// workgroups, one per CU: two of the workgroup's own waves, 256 registers each (`rm_claim_half_simd`), fill every SIMD, and no wave leaves
+// before all have finished (`__syncthreads()` at the end), so no foreign wave ever shares a SIMD with a running MLP.  The fp32 forms
+// (v_mfma_f32_16x16x4_f32 was never observed as a neighbour that matters) keep 4-wave workgroups, two per CU.
+template <bool SPLIT> struct RmWaves { static constexpr int value = SPLIT ? 8 : 4; };
+template <bool SPLIT> __device__ __forceinline__ void rm_claim_half_simd() { if constexpr (SPLIT) asm volatile("" ::: "v255"); }
+
 template <int C, int HID, bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * RmWaves<SPLIT>::value, 2)
 render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
     using K = RmCfg<C, HID>;
+    constexpr int NW = RmWaves<SPLIT>::value;
+    rm_claim_half_simd<SPLIT>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
     unsigned char* s_tex = s_geo + MlpBytes<C, HID, SPLIT>::value;
@@ -516,7 +526,7 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
         int s0n = s0 + 16, nn = n, rn = r;
         int64_t rayn = ray;
         if (s0n >= S) {
-            s0n = 0; rayn = ray + 4; rn = r + 4;
+            s0n = 0; rayn = ray + NW; rn = r + NW;
             while (rn >= p.rays_per_img) { rn -= (int)p.rays_per_img; ++nn; }
         }
         const bool haven = rayn < ray_end;
@@ -610,6 +620,7 @@ render_rays_kernel(ide3d_render_params p, int64_t rays_per_block) {
         }
         ray = rayn; n = nn; r = rn; s0 = s0n; have = haven;
     }
+    if constexpr (SPLIT) __syncthreads();          // exclusive residency: nobody leaves while another wave of the workgroup still multiplies
 }
 
 // Where sample_voxel takes its points from: an [n, m, 3] array, or the extract_shapes.py lattice generated in registers.
@@ -650,14 +661,16 @@ __global__ void lattice_points_kernel(Src src, int64_t count, float* __restrict_
 
 // sample_voxel: gathers + MLPs for arbitrary points, rows of [feat | seg | sigma] (or sigma only).
 template <int C, int HID, class Src, bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * RmWaves<SPLIT>::value, 2)
 sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restrict__ out, int64_t tiles_per_block) {
     using K = RmCfg<C, HID>;
+    constexpr int NW = RmWaves<SPLIT>::value;
+    rm_claim_half_simd<SPLIT>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MB = MlpBytes<C, HID, SPLIT>::value;
     unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
     unsigned char* s_tex = s_geo + MB;
-    float* s_stage = reinterpret_cast<float*>(s_geo + 2 * MB);                 // [4 waves][16 samples][width] row staging
+    float* s_stage = reinterpret_cast<float*>(s_geo + 2 * MB);                 // [NW waves][16 samples][width] row staging
     stage_branch<C, HID, SPLIT>(s_geo, p.geo_w0, p.geo_b0, p.geo_w1, p.geo_b1, 1 + p.seg_ch);
     stage_branch<C, HID, SPLIT>(s_tex, p.tex_w0, p.tex_b0, p.tex_w1, p.tex_b1, p.feat_ch);
     __syncthreads();
@@ -710,7 +723,7 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m, float* __re
     }
     while (have) {
         const int64_t row0 = tile * 16;
-        const int64_t tilen = tile + 4;
+        const int64_t tilen = tile + NW;
         const bool haven = tilen < tile_end;
         const int n0c = n0, dnc = dn;
         // next tile's points first (PointsFromMemory: three small loads, ahead of the taps that fly across the MLPs).  The prefetch is
@@ -752,6 +765,7 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m, float* __re
         __builtin_amdgcn_wave_barrier();
         tile = tilen; have = haven;
     }
+    if constexpr (SPLIT) __syncthreads();          // exclusive residency (see render_rays_kernel)
 }
 
 // Densities only (extract_shapes.py's cube, sample_voxel(sigma_only)): one gather, the hidden layer, row 0 of the second layer.  The
@@ -760,9 +774,11 @@ sample_voxel_kernel(ide3d_render_params p, const Src src, int64_t m, float* __re
 // `super tile`), and each of its four 16-row tiles fetches its own from the lanes that hold them (ds_bpermute: 25 values per tile
 // instead of ~300 vector instructions).  Same software pipeline as above: the taps of the next tile fly during the MLP of this one.
 template <int C, int HID, class Src, bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * RmWaves<SPLIT>::value, 2)
 density_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restrict__ out_sigma, int64_t supers_per_block) {
     using K = RmCfg<C, HID>;
+    constexpr int NW = RmWaves<SPLIT>::value;
+    rm_claim_half_simd<SPLIT>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned char* s_geo = reinterpret_cast<unsigned char*>(lds);
     float* const s_row = reinterpret_cast<float*>(s_geo + MlpBytes<C, HID, SPLIT>::value);     // row 0 of geo_w1 + its bias
@@ -813,7 +829,7 @@ density_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restric
     };
 
     int64_t st = super_begin + wid;
-    if (st >= super_end) return;
+    if (st < super_end) {
     TapAddr tl[3], t[3];
     TapBuf<C> buf;
     int dnl, dn;
@@ -821,7 +837,7 @@ density_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restric
     tile_taps(tl, dnl, 0, t, dn);
     issue_taps<C>(uniform_ptr(p.geo_planes + n0 * p.geo_stride[0]), t, gl, buf, (unsigned)dn * geo_img_b);
     while (st < super_end) {
-        const int64_t stn = st + 4;
+        const int64_t stn = st + NW;
         const int64_t stp = stn < super_end ? stn : st;              // the prefetch past the last super tile re-reads this one
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -839,19 +855,22 @@ density_kernel(ide3d_render_params p, const Src src, int64_t m, float* __restric
         }
         st = stn;
     }
+    }
+    if constexpr (SPLIT) __syncthreads();          // exclusive residency (see render_rays_kernel)
 }
 
 template <int C, int HID, bool SPLIT = false>
 static int launch_render(const ide3d_render_params& p, hipStream_t st) {
     const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value;
     const int64_t total_rays = (int64_t)p.n * p.rays_per_img;
-    int64_t nblk = kNumCU * 2;
-    int64_t rpb = cdiv64(cdiv64(total_rays, nblk), 4) * 4;
-    if (rpb < 4) rpb = 4;
+    constexpr int NW = RmWaves<SPLIT>::value;
+    int64_t nblk = kNumCU * 8 / NW;                                // 8 waves per CU either way
+    int64_t rpb = cdiv64(cdiv64(total_rays, nblk), NW) * NW;
+    if (rpb < NW) rpb = NW;
     nblk = cdiv64(total_rays, rpb);
     auto kern = render_rays_kernel<C, HID, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, rpb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, rpb);
     IDE3D_CHECK_LAUNCH("render_rays");
     return IDE3D_OK;
 }
@@ -859,6 +878,7 @@ static int launch_render(const ide3d_render_params& p, hipStream_t st) {
 template <int C, int HID, class Src, bool SPLIT = false>
 static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m, float* out, float* out_sigma,
                         int sigma_only, hipStream_t st) {
+    constexpr int NW = RmWaves<SPLIT>::value;
     // a lane whose row lies in a later image than the first row of its (super) tile adds whole image strides to its 32-bit byte
     // offsets: at most rows_per_tile - 1 images when m = 1
     {
@@ -870,26 +890,26 @@ static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m,
     if (sigma_only) {
         const size_t lds_bytes = (size_t)MlpBytes<C, HID, SPLIT>::value + (size_t)(HID + 4) * sizeof(float);
         const int64_t nsuper = cdiv64((int64_t)p.n * m, 64);
-        int64_t nblk = kNumCU * 2;
-        int64_t spb = cdiv64(cdiv64(nsuper, nblk), 4) * 4;
-        if (spb < 4) spb = 4;
+        int64_t nblk = kNumCU * 8 / NW;
+        int64_t spb = cdiv64(cdiv64(nsuper, nblk), NW) * NW;
+        if (spb < NW) spb = NW;
         nblk = cdiv64(nsuper, spb);
         auto kern = density_kernel<C, HID, Src, SPLIT>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out_sigma, spb);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out_sigma, spb);
         IDE3D_CHECK_LAUNCH("sample_voxel (densities)");
         return IDE3D_OK;
     }
     const int width = p.feat_ch + p.seg_ch + 1;
-    const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value + (size_t)4 * 16 * width * sizeof(float);
+    const size_t lds_bytes = (size_t)2 * MlpBytes<C, HID, SPLIT>::value + (size_t)NW * 16 * width * sizeof(float);
     const int64_t ntiles = cdiv64((int64_t)p.n * m, 16);
-    int64_t nblk = kNumCU * 2;
-    int64_t tpb = cdiv64(cdiv64(ntiles, nblk), 4) * 4;
-    if (tpb < 4) tpb = 4;
+    int64_t nblk = kNumCU * 8 / NW;
+    int64_t tpb = cdiv64(cdiv64(ntiles, nblk), NW) * NW;
+    if (tpb < NW) tpb = NW;
     nblk = cdiv64(ntiles, tpb);
     auto kern = sample_voxel_kernel<C, HID, Src, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, p, src, m, out, tpb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out, tpb);
     IDE3D_CHECK_LAUNCH("sample_voxel");
     return IDE3D_OK;
 }

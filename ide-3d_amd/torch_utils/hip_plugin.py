@@ -862,19 +862,18 @@ _ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'f16x3': 16, 'default': 0}
 
 
 def conv_arithmetic(name=None):
-    """Get (no argument) or set the process-wide arithmetic of the shared-weight 3x3 convolutions: 'fp32' (exact fp32 products on
-    the fp32 MFMA; the default), 'bf16x6' (3 bf16 pieces per operand, 6 products: fp32-grade), 'f16x3' (2 fp16 pieces, 3 products,
-    power-of-two range scales from the producers' `amax`: ~2^-21 per product relative to the row / image maxima), 'bf16x3' (2 bf16
-    pieces, 3 products, ~2^-17 per product) or 'default' (back to the IDE3D_CONV_ARITH environment default, else fp32).  Returns the
-    name in force.
+    """Get (no argument) or set the process-wide arithmetic of the shared-weight 3x3 convolutions (the per-image heads and the decoder MLPs of
+    the ray-marcher follow it): 'bf16x6' (the default: every fp32 operand as 3 bf16 pieces, the 6 products above 2^-24 on the bf16 matrix
+    pipe, fp32 accumulation - fp32-grade, measured as accurate as the fp32 matrix instruction against float64), 'fp32' (exact fp32
+    products on v_mfma_f32_32x32x2_f32, 1.5x slower end to end), 'f16x3' (2 fp16 pieces, 3 products, power-of-two range scales from the
+    producers' `amax`: ~2^-21 per product relative to the row / image maxima; the fastest fp32-grade mode), 'bf16x3' (2 bf16 pieces, 3
+    products, ~2^-17 per product) or 'default' (back to the IDE3D_CONV_ARITH environment default, else bf16x6).  Returns the name in force.
 
-    The split arithmetics are OPT-IN.  On MI355X a wave of another kernel that executes packed fp32 VALU instructions (v_pk_fma_f32,
-    v_pk_mul_f32, v_pk_add_f32 — what hipcc / ATen emit for vectorised fp32 code) on the same SIMD beside one of these LDS-fed
-    bf16 / fp16 MFMA loops was measured to return wrong values (scripts/micro/pk_mfma_hazard.cpp).  This library
-    is built without such instructions, so its own kernels are safe next to each other; kernels of OTHER libraries (ATen
-    element-wise ops, RCCL, another tenant) running concurrently on another stream of the same GPU are not.  Select a split
-    arithmetic only where the convolutions own the GPU while they run — the render path does (one stream + its own side branch):
-    `GraphedRenderer(..., conv_arithmetic=...)`, `bench.py --conv-arith` — or build the library with -DIDE3D_SP_EXCLUSIVE_SIMD."""
+    Safety beside other kernels: on MI355X a packed-fp32 instruction of ANOTHER kernel's wave returns wrong values
+    while a wave on the same SIMD runs a loop of LDS reads + bf16 / fp16 MFMAs.  Every kernel of this library with such a loop keeps
+    foreign waves off its SIMDs while the loop runs (8-wave workgroups that fill the register file of their SIMDs, or waves that claim
+    all 512 registers), so every arithmetic may run beside kernels of other libraries, RCCL or another stream
+    (tests/test_gpu_conv_arith.py::test_foreign_packed_fp32_victim_beside_every_matrix_loop)."""
     lib = load()
     if name is not None:
         _require(name in _ARITH_NAMES, f'conv_arithmetic: one of {sorted(_ARITH_NAMES)}')

@@ -393,11 +393,12 @@ int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
  *      staged), both undone together with the demodulation in the epilogue.  Operands more than 2^17 below their row / image
  *      maximum lose relative (not absolute) precision: an fp16 piece cannot be smaller than 2^-24 of the scaled range.  Needs
  *      `x_amax`; without it the launch runs in bf16x6;
- *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3 | f16x3, else fp32.  The split
- *      arithmetics are opt-in: a wave of ANOTHER kernel that executes packed fp32 VALU instructions (v_pk_fma_f32 ...) on the
- *      same SIMD beside an LDS-fed bf16 / fp16 MFMA loop was measured to return wrong results on MI355X (DESIGN.md section 4.2;
- *      this library contains no such instructions), so a caller selects them only where no foreign kernel shares the GPU with the
- *      convolutions — the render path does (`GeneratorSpec.conv_arithmetic`, `bench.py --conv-arith`).
+ *   0  back to the process default: environment IDE3D_CONV_ARITH = fp32 | bf16x6 | bf16x3 | f16x3, else bf16x6 (round 4; fp32 before).
+ *      A wave of ANOTHER kernel that executes packed fp32 VALU instructions (v_pk_fma_f32 ...) on operands fresh from global memory
+ *      returns wrong results on MI355X while a wave on the same SIMD runs a loop of LDS reads + bf16 / fp16 MFMAs.
+ *      Every kernel of this library that contains such a loop keeps foreign waves off its SIMDs for as long as the loop runs (8-wave
+ *      workgroups whose waves hold 256 registers each, or waves that claim all 512 registers of their SIMD: "exclusive residency"), so
+ *      every arithmetic may run beside kernels of other libraries on other streams.
  * The same switch selects the arithmetic of per-image 1x1 heads with <= 32 or 161..192 outputs on grids of >= 512 workgroups, and of the
  * two decoder MLPs inside ide3d_render_rays / ide3d_sample_voxel / ide3d_density_lattice at C = 32, hidden = 64: exact fp32 products
  * on v_mfma_f32_16x16x4_f32 with fp32 (1) selected, bf16x6 (fp32-grade, 3 bf16 pieces per operand on v_mfma_f32_16x16x32_bf16)

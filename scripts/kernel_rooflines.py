@@ -222,6 +222,11 @@ def cases(device):
     conv_case('modconv transposed 3x3 256->128 in@128', 256, 128, 128, mode=2)
     conv_case('modconv transposed 3x3 128->64 in@256', 128, 64, 256, mode=2)
     conv_case('modconv transposed 3x3 32->128 in@128 (b256.conv0)', 32, 128, 128, mode=2)
+    # the low-resolution half of the backbone (4^2 .. 32^2 at batch 4: a few dozen workgroups + split-K each)
+    for res in (32, 16, 8):
+        conv_case(f'modconv 3x3 512->512 @{res} (low-res backbone)', 512, 512, res)
+    for res in (32, 16, 8, 4):
+        conv_case(f'modconv transposed 3x3 512->512 in@{res} (low-res backbone)', 512, 512, res, mode=2)
     conv_case('conv 3x3 stride 2 64->128 in@257 (encoder)', 64, 128, 257, mode=1)
     for cin, cout, res in ((128, 192, 256), (256, 192, 128), (64, 22, 512), (128, 22, 256)):
         xx = rn(N, cin, res, res); ww = rn(N, cout, cin, 1, 1); bz = rn(cout)

@@ -7,6 +7,8 @@
 //               3 same, s_nop 7 x2 between the LDS wait and the first MFMA     4 same LDS reads, MFMA on register constants (reads kept live by VALU)
 //               5 LDS-fed with ds_read_b64 pairs         6 LDS-fed v_mfma_f32_32x32x16_f16       7 LDS reads + VALU only (no MFMA)
 //               8 LDS-fed, one s_nop 1 after every MFMA  9 LDS-fed 16x16x32 bf16
+//               a / b : neighbour 4's loop in ONE-wave workgroups, 2 per CU: (a) claims all 512 registers of its SIMD, so the victim's waves share
+//               the CU (LDS, L1, TA, scalar cache) but never the SIMD; (b) the same without the claim (positive control)
 //   victims     B  fmaf source, SLP-packed (baseline)    M  same, every loaded value copied through v_mov_b32 before use
 //               R  pure register v_pk_fma_f32 chain (no memory operands in the loop)     S  scalar v_fma_f32 on the same loads (control)
 // For the first failing values it prints got / expected / xor so the kind of corruption is visible.
@@ -72,6 +74,31 @@ __global__ void __launch_bounds__(256) neighbour(float* out, int iters) {
     out[blockIdx.x * 256 + l] = s;
 }
 
+
+// SIMD-locality check: one-wave workgroups running neighbour 4's loop (LDS reads kept live by VALU + MFMAs on register constants, the
+// variant that corrupts victim B most).  CLAIM = 1: the wave claims v255 + a255 = the whole 512-register file of its SIMD.
+template <int CLAIM>
+__global__ void __launch_bounds__(64) neighbour_1wave(float* out, int iters) {
+    if (CLAIM) asm volatile("" ::: "v255", "a255");
+    __shared__ u32x4 lds[2048];
+    const unsigned l = threadIdx.x;
+    for (int i = l; i < 2048; i += 64) lds[i] = u32x4{0x3f803f80u + (unsigned)i, 0x3f003f00u, 0x3e803e80u, 0x3f803f00u + (unsigned)(i << 3)};
+    __syncthreads();
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const u32x4 ca = {0x3f803f80u + (l << 8), 0x3f003f00u, 0x3e803e80u + l, 0x3f803f00u}, cb = {0x3f003f80u, 0x3e803f00u + (l << 4), 0x3f803f80u, 0x3f003f00u};
+    unsigned live = 0;
+    for (int i = 0; i < iters; ++i) {
+        const u32x4 a0 = lds[(l + i * 64) & 2047], a1 = lds[(l + i * 64 + 512) & 2047], b0 = lds[(l * 3 + i) & 2047], b1 = lds[(l * 5 + i + 1024) & 2047];
+        live ^= a0[0] ^ a1[1] ^ b0[2] ^ b1[3] ^ a0[3] ^ b1[0];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca), __builtin_bit_cast(bf16x8, cb), acc[t], 0, 0, 0);
+    }
+    float s = __uint_as_float(live & 0x3fffffffu);
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 64 + l] = s;
+}
+
 // y[row] = sum_k A[row, k] * x[k]; a wave owns 8 rows, lanes stride over k (the fmaf source that hipcc SLP-packs into v_pk_fma_f32)
 template <int V>      // 0 = B (packed), 1 = M (loaded values through v_mov first), 3 = S (scalar fma, control: no SLP)
 __global__ void __launch_bounds__(256) dot_rows(const float* __restrict__ A, const float* __restrict__ x, float* __restrict__ y, int K) {
@@ -120,7 +147,7 @@ int main(int argc, char** argv) {
     const int K = 512, ROWS = 64 * 4 * 8;
     const int REPS = argc > 1 ? atoi(argv[1]) : 3000;
     const char* only_v = argc > 2 ? argv[2] : "BMRS";
-    const char* only_n = argc > 3 ? argv[3] : "0123456789";
+    const char* only_n = argc > 3 ? argv[3] : "0123456789ab";
     const int NOUT = 64 * 256;                     // outputs per victim launch (rows for the dot kernels use the first ROWS)
     std::vector<float> hA((size_t)ROWS * K), hx(K);
     unsigned s = 12345;
@@ -138,8 +165,8 @@ int main(int argc, char** argv) {
     for (int vi = 0; vi < 4; ++vi) {
         if (!strchr(only_v, vict[vi])) continue;
         const int nout = vict[vi] == 'R' ? NOUT : ROWS;
-        for (int nb = 0; nb <= 9; ++nb) {
-            if (!strchr(only_n, '0' + nb)) continue;
+        for (int nb = 0; nb <= 11; ++nb) {
+            if (!strchr(only_n, nb < 10 ? '0' + nb : 'a' + nb - 10)) continue;
             auto victim = [&](float* out) {
                 switch (vict[vi]) {
                 case 'B': hipLaunchKernelGGL(dot_rows<0>, dim3(64), dim3(256), 0, sb, dA, dx, out, K); break;
@@ -163,6 +190,8 @@ int main(int argc, char** argv) {
                     case 6: hipLaunchKernelGGL(neighbour<6>, dim3(1024), dim3(256), 0, sa, dspin, it); break;
                     case 7: hipLaunchKernelGGL(neighbour<7>, dim3(1024), dim3(256), 0, sa, dspin, it * 4); break;
                     case 8: hipLaunchKernelGGL(neighbour<8>, dim3(1024), dim3(256), 0, sa, dspin, it); break;
+                    case 10: hipLaunchKernelGGL(neighbour_1wave<1>, dim3(512), dim3(64), 0, sa, dspin, it * 4); break;
+                    case 11: hipLaunchKernelGGL(neighbour_1wave<0>, dim3(512), dim3(64), 0, sa, dspin, it * 4); break;
                     case 9: hipLaunchKernelGGL(neighbour<9>, dim3(1024), dim3(256), 0, sa, dspin, it * 2); break;
                     }
                 }
@@ -184,7 +213,7 @@ int main(int argc, char** argv) {
                     }
                 bad_launches += b != 0; bad_values += b;
             }
-            printf("victim %c beside neighbour %d: %4d of %d launches differ (%ld values)\n", vict[vi], nb, bad_launches, REPS, bad_values);
+            printf("victim %c beside neighbour %x: %4d of %d launches differ (%ld values)\n", vict[vi], nb, bad_launches, REPS, bad_values);
             fflush(stdout);
         }
     }

@@ -93,7 +93,7 @@ def test_epilogue_and_split_k_agree_between_arithmetics(gpu_device):
 def _env_default_only():
     import os
     if os.environ.get('IDE3D_CONV_ARITH'):
-        pytest.skip('asserts the library default (fp32); IDE3D_CONV_ARITH overrides it in this process')
+        pytest.skip('asserts the library default (bf16x6); IDE3D_CONV_ARITH overrides it in this process')
 
 
 def test_default_arithmetic_switch(gpu_device):
@@ -103,7 +103,7 @@ def test_default_arithmetic_switch(gpu_device):
     try:
         x, w, s, d = _operands((1, 64, 64, 20, 20, 0), gpu_device)      # cin > 32: narrower layers always take the fp32 loop
         outs = {}
-        assert before == 'fp32', 'the split arithmetics are opt-in: the process default is exact fp32'
+        assert before == 'bf16x6', 'the process default is the fp32-grade bf16x6 arithmetic (exclusive residency makes it safe beside foreign kernels)'
         for name, code in ARITH.items():
             assert hip_plugin.conv_arithmetic(name) == name
             amax = {'x_amax': _finite_amax(x)} if name == 'f16x3' else {}
@@ -389,17 +389,13 @@ def test_adversarial_beyond_bf16_and_non_finite_operands(gpu_device):
 
 
 def test_foreign_aten_kernels_beside_the_convolutions(gpu_device):
-    """kernels of OTHER libraries next to the convolutions.  Victims: ATen element-wise / reduction kernels (hipcc emits packed
-    fp32 VALU instructions for them) on stream B while stream A loops a convolution.
-      * default arithmetic (fp32 MFMA): the victims must be bit-stable — this is why fp32 is the process default;
-      * split arithmetics (opt-in): the outcome is RECORDED, not asserted (profiles/round3/aten_victims.json via gpurun_out): round 2
-        measured wrong results in packed-fp32 victims beside an LDS-fed bf16 MFMA loop; callers select a split
-        arithmetic only where no foreign kernel runs beside the convolutions, or build with -DIDE3D_SP_EXCLUSIVE_SIMD."""
-    _env_default_only()
+    """kernels of OTHER libraries next to the convolutions.  Victims: ATen element-wise / reduction kernels on stream B while
+    stream A loops a convolution, in every arithmetic.  Since round 4 the matrix loops of the split arithmetics keep foreign waves off
+    their SIMDs (exclusive residency), so the victims must be bit-stable beside ALL of them; the counts are also
+    written to gpurun_out/aten_victims.json.  (The susceptible foreign kernel is tests/native/pk_victim.hip: next test.)"""
     import json, os
     from torch_utils import hip_plugin
     dev = gpu_device
-    assert hip_plugin.conv_arithmetic() == 'fp32'
     g = torch.Generator().manual_seed(6)
     rn = lambda *sh: torch.randn(*sh, generator=g).to(dev)
     x = rn(4, 64, 256, 256); wt = rn(64, 64, 3, 3); s = rn(4, 64) + 1; d = torch.rand(4, 64, generator=g).to(dev)
@@ -432,12 +428,112 @@ def test_foreign_aten_kernels_beside_the_convolutions(gpu_device):
             torch.cuda.synchronize(dev)
             bad = sum(1 for o in outs if not torch.equal(o, ref))
             record[f'{arith}/{name}'] = {'launches': len(outs), 'changed': bad}
-            if arith == 'fp32':
-                assert bad == 0, f'{name}: {bad} of {len(outs)} ATen launches changed beside the fp32-MFMA convolution'
+            assert bad == 0, f'{name}: {bad} of {len(outs)} ATen launches changed beside the {arith} convolution'
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, 'aten_victims.json'), 'w') as f:
         json.dump(record, f, indent=1)
+
+
+def _pk_victim_lib():
+    import ctypes, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'native', '_bin', 'libpk_victim.so')
+    if not os.path.isfile(path):
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import __graft_entry__
+        path = __graft_entry__.build_test_natives()
+    lib = ctypes.CDLL(path)
+    lib.pk_victim_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.pk_aggressor_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+def test_foreign_packed_fp32_victim_beside_every_matrix_loop(gpu_device):
+    """DESIGN.md section 4.2, round 4.  tests/native/pk_victim.hip is a FOREIGN kernel with the susceptible pattern (v_pk_fma_f32 on operands
+    straight from global loads; built with packed fp32 ON, unlike the library).
+      positive control   beside a stand-alone LDS-read + bf16 MFMA loop whose waves SHARE SIMDs with it, its results change in most launches
+                         (if the control shows nothing on this box the test is skipped: nothing to protect against);
+      the library        beside every kernel of this library that contains an LDS-fed bf16 / fp16 matrix loop - the 3x3 and transposed
+                         3x3 convolutions in bf16x6 / f16x3 / bf16x3 in their 8-wave, whole-SIMD-claiming and low-resolution forms, the
+                         per-image heads, the fused ray-marcher and sample_voxel with bf16x6 MLPs - every one of 1500 victim launches per
+                         neighbour must equal the result computed alone, bit for bit: exclusive residency keeps foreign waves off the
+                         SIMDs those loops run on."""
+    from torch_utils import hip_plugin
+    from training import triplane, volumetric_rendering as vr
+    lib = _pk_victim_lib()
+    dev = gpu_device
+    g = torch.Generator().manual_seed(12)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    K, BLOCKS, REPS = 512, 64, 1500
+    A = rn(BLOCKS * 32, K); xv = rn(K)
+    ref = torch.empty(BLOCKS * 32, device=dev)
+    ys = torch.empty(REPS, BLOCKS * 32, device=dev)
+    spin = torch.empty(1024 * 256, device=dev)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+
+    def victim(out, stream):
+        assert lib.pk_victim_launch(A.data_ptr(), xv.data_ptr(), out.data_ptr(), K, BLOCKS, stream.cuda_stream) == 0
+
+    victim(ref, sb)
+    torch.cuda.synchronize(dev)
+
+    def changed_launches(neighbour, every=25):
+        """REPS victim launches on stream B while `neighbour()` keeps stream A busy; number of launches whose result differs from `ref`."""
+        ys.zero_()
+        torch.cuda.synchronize(dev)
+        for i in range(REPS):
+            if i % every == 0:
+                with torch.cuda.stream(sa):
+                    neighbour()
+            victim(ys[i], sb)
+        torch.cuda.synchronize(dev)
+        return int((ys != ref[None]).any(dim=1).sum())
+
+    control = changed_launches(lambda: lib.pk_aggressor_launch(spin.data_ptr(), 1500, 1024, sa.cuda_stream), every=40)
+    if control == 0:
+        pytest.skip('the stand-alone aggressor does not disturb the packed-fp32 victim on this device: nothing to protect against')
+    assert changed_launches(lambda: None) == 0, 'the victim must be stable on its own'
+
+    record = {'positive_control_changed_launches': control, 'launches_per_neighbour': REPS}
+    neighbours = {}
+    # convolutions: (cin, cout, res, mode) covering the 8-wave 16 x 16 form, the 64-row 16 x 16 form, 8 x 16 with the whole SIMD claimed, the
+    # transposed 8-wave forms, the 4 x 16 transposed form and a low-resolution split-K layer
+    for cin, cout, res, mode in ((128, 128, 256, 0), (64, 64, 512, 0), (512, 512, 64, 0), (256, 128, 128, 2), (128, 64, 256, 2), (512, 256, 64, 2), (512, 512, 16, 2)):
+        x = rn(4, cin, res, res); wt = rn(cout, cin, 3, 3); s = rn(4, cin) + 1; d = torch.rand(4, cout, generator=g).to(dev)
+        xam = _finite_amax(x)
+        for arith, code in (('bf16x6', 6), ('f16x3', 16), ('bf16x3', 3)):
+            neighbours[f'conv {cin}->{cout} @{res} mode {mode} [{arith}]'] = \
+                (lambda x=x, wt=wt, s=s, d=d, xam=xam, mode=mode, code=code: _mc()(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=mode, arith=code, x_amax=xam))
+    for cin, cout, res in ((128, 192, 256), (64, 22, 512)):
+        x = rn(4, cin, res, res); wt = rn(4, cout, cin, 1, 1); bz = rn(cout)
+        neighbours[f'heads {cin}->{cout} @{res} [bf16x6]'] = (lambda x=x, wt=wt, bz=bz: _mc()(x, wt, None, None, None, 0.0, bz, 1, 0.0, 1.0, 256.0, arith=6))
+    # fused ray-marcher / sample_voxel with bf16x6 MLPs (they follow the process arithmetic)
+    torch.manual_seed(1)
+    R = triplane.TriplaneRenderer(triplane.GeneratorSpec()).to(dev).eval()
+    tex = rn(4, 96, 256, 256).contiguous(memory_format=torch.channels_last); geo = rn(4, 96, 256, 256).contiguous(memory_format=torch.channels_last)
+    cam = torch.cat([triplane.camera_label(y, device=dev) for y in (-0.5, 0.0, 0.5, 0.25)])[:, :16].reshape(-1, 4, 4)
+    try:
+        hip_plugin.conv_arithmetic('bf16x6')
+        with torch.no_grad():
+            R(tex, geo, cam, jitter=False)                              # warm (workspaces, plugin init) outside the measured window
+        neighbours['render_rays [bf16x6 MLPs]'] = lambda: R(tex, geo, cam, jitter=False)
+        before = hip_plugin.CALLS.get('render_rays', 0)
+        for name, fn in neighbours.items():
+            with torch.no_grad():
+                bad = changed_launches(fn)
+            record[name] = bad
+        assert hip_plugin.CALLS.get('render_rays', 0) > before
+    finally:
+        hip_plugin.conv_arithmetic('default')
+    import json, os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, 'pk_victim_beside_library.json'), 'w') as f:
+        json.dump(record, f, indent=1)
+    hit = {k: v for k, v in record.items() if k not in ('positive_control_changed_launches', 'launches_per_neighbour') and v}
+    assert not hit, f'foreign packed-fp32 victim disturbed beside: {hit} (positive control: {control} of {REPS})'
 
 
 def test_amax_is_dropped_when_the_activation_is_edited_in_place(gpu_device):
