@@ -958,12 +958,14 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 // [row][8], double-buffered LDS-DMA).  The accumulator layout has lane = pixel, so every store instruction writes 128-byte runs.
 // Exclusive residency (see kSpExclusive below): 8 waves = two of this workgroup's waves per SIMD, 256 pixels per workgroup, one workgroup
 // per CU; every wave stays until the barrier behind the K loop.
-constexpr int kHeadWaves = 8;
+// MT = 1 (<= 32 outputs: HBM-bound, ~100 registers): 16 waves of 128 registers, four per SIMD, 512 pixels per workgroup - the loads of twice
+// as many waves in flight (116 -> see profiles/round4 at 64 -> 22 @512 with 8 waves; the 4-wave form of round 3 ran two workgroups per CU).
+constexpr int head_waves(int mt) { return mt == 1 ? 16 : 8; }
 template <int PARTS, int MT>
 struct HeadCfg {
     static constexpr int ROWS = MT * 32;
     static constexpr int A_UNITS = PARTS * 2 * ROWS;                  // 16-byte units per 16-channel chunk
-    static constexpr int NWV = kHeadWaves;
+    static constexpr int NWV = head_waves(MT);
     static constexpr int BN = 32 * NWV;
 };
 __host__ __device__ inline int64_t head_packed_units(int n, int cchunks, int parts, int mt) { return (int64_t)n * cchunks * parts * 2 * mt * 32; }
@@ -997,10 +999,10 @@ head_pack_split_kernel(const float* __restrict__ w, int64_t w_batch_stride, int 
 }
 
 template <int PARTS, int MT>
-__global__ void __launch_bounds__(64 * kHeadWaves, 2)        // two waves per SIMD, both of this workgroup (<= 256 registers each)
+__global__ void __launch_bounds__(64 * head_waves(MT), head_waves(MT) / 4)        // 2 (4) waves per SIMD, all of this workgroup, 256 (128) registers each
 head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchunks, int tiles_per_image) {
     using K = HeadCfg<PARTS, MT>;
-    asm volatile("" ::: "v255");                                             // each wave holds half of its SIMD's register file: no foreign wave fits
+    if constexpr (K::NWV == 16) asm volatile("" ::: "v127"); else asm volatile("" ::: "v255");      // the workgroup's waves hold their SIMDs' whole register file: no foreign wave fits
     constexpr int S_MIN = K::NWV * 32 * 40 / 4 + 2 * K::ROWS / 4 + 16;       // the epilogue's staging tiles: 32 rows x (32 + 8) floats per wave
     constexpr int S_UNITS = (2 * K::A_UNITS > S_MIN) ? 2 * K::A_UNITS : S_MIN;
     __shared__ __attribute__((aligned(16))) u32x4 s_a[S_UNITS];              // weights of chunk c and c + 1 (L2-resident, one chunk of look-ahead)
@@ -1375,6 +1377,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 const int64_t b8 = (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n, b16 = (int64_t)pl.mblocks * cdiv(p.h + 1, 16) * cdiv(p.w_ + 1, 16) * p.n;
                 if (pl.big == 1) pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
                 else if (b16 >= 2 * kNumCU) pl.tile = 7;
+                else if (p.h <= 16 && p.w_ <= 16) pl.tile = 6;       // 4^2 .. 16^2 maps (split-K): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves: 115 / 47 / 31)
             }
         }
         if (pl.mode == MODE_CONV3) {
@@ -1481,7 +1484,7 @@ static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
     static const bool off = getenv("IDE3D_MODCONV_HEAD_FP32") != nullptr;
     return !off && arith != 1 && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 &&
            (p.cout <= 32 || (p.cout > 160 && p.cout <= 192)) && p.cin >= 32 &&
-           (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 32 * ide3d::kHeadWaves) >= ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
+           (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 32 * ide3d::head_waves(p.cout <= 32 ? 1 : 6)) >= ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
                                                                               // (512 channels @32^2 / @64^2: 54 us against 16 / 40 us on the fp32 loop)
 }
 
@@ -1536,10 +1539,10 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         IDE3D_CHECK_ARG(p.workspace_bytes >= head_packed_units(p.n, cchunks, parts, mt) * 16, "modconv2d: workspace too small for the packed head weights");
         u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
         const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
-        const int tiles = cdiv(p.h * p.w_, 32 * kHeadWaves);
+        const int tiles = cdiv(p.h * p.w_, 32 * head_waves(mt));
 #define IDE3D_HEAD(P, M) do { \
             hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
-            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * kHeadWaves), 0, st_head, p, wu, cchunks, tiles); } while (0)
+            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * head_waves(M)), 0, st_head, p, wu, cchunks, tiles); } while (0)
         if (parts == 2) { if (mt == 1) IDE3D_HEAD(2, 1); else IDE3D_HEAD(2, 6); }
         else            { if (mt == 1) IDE3D_HEAD(3, 1); else IDE3D_HEAD(3, 6); }
 #undef IDE3D_HEAD
