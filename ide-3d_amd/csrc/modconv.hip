@@ -187,9 +187,12 @@ __device__ __forceinline__ void amax_commit(float* y_amax, int n, float v, bool)
 template <int MODE, int TI, int PH, int PW, int NWV, int NCLS, int MTW, int NTW, int BM, int SCRATCH>
 __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, float* __restrict__ partial, const ConvGeom& g,
                                                f32x16 (&acc)[NCLS][MTW][NTW], float* s_w, int mb, int n0, int y0, int x0, int split, int cls,
-                                               int wm, int wn, int lp, const float* __restrict__ row_unscale = nullptr, float x_unscale = 1.f) {
+                                               int wm, int wn, int lp, const float* __restrict__ row_unscale = nullptr, float x_unscale = 1.f,
+                                               int team_tid = -1, float* amax_scratch = nullptr) {
+    // team_tid >= 0: this tile belongs to one of two 64 * NWV-thread teams of the workgroup (modconv_split_kernel<..., TEAMS = 2>): thread
+    // index inside the team; s_w is the team's own LDS, amax_scratch the workgroup's (both teams work on the same image)
     constexpr int NT = 64 * NWV;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int tid = team_tid >= 0 ? team_tid : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
     const int cpy = cls >> 1, cpx = cls & 1;
     const bool raw = (g.split_k > 1);
     // Demodulation coefficients and biases of this block's BM output channels go to LDS first (the K loop has finished with
@@ -310,7 +313,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
     }
     }
     if (TI == 1 && p.y_amax != nullptr && !raw && n0 < p.n)        // (uniform over the workgroup) one read / atomic per tile
-        amax_raise_block(p.y_amax, n0, amax_tile, s_w);          // its first barrier: every thread has finished reading s_dm / s_bi / T
+        amax_raise_block(p.y_amax, n0, amax_tile, amax_scratch ? amax_scratch : s_w);          // its first barrier: every thread has finished reading s_dm / s_bi / T
 }
 
 // One output tile: `tl` = index inside its tile set (row-major, `tiles_x` per row), `cls` = output parity class
@@ -719,14 +722,17 @@ template <int PENDING>
 __device__ __forceinline__ void lds_wait128(u32x4& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
 __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16>
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16, int TEAMS = 1>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
                                                    const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x,
-                                                   const float* __restrict__ row_unscale) {
+                                                   const float* __restrict__ row_unscale, float* wg_scratch = nullptr) {
     using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
     static_assert(!F16 || PARTS == 2, "f16x3 = two fp16 pieces per operand");
+    static_assert(TEAMS == 1 || (TEAMS == 2 && NWV == 4), "two teams of four waves, or one team");
     constexpr int PW = K::PW;
-    const int tid = threadIdx.x, lane = tid & 63;
+    // TEAMS = 2: two 4-wave teams in one 8-wave workgroup, each with its own tile (adjacent output-channel blocks of the same pixels, so
+    // both run the same number of stages) and its own LDS; the workgroup barriers couple them, the code below is per team
+    const int tid = (TEAMS == 2) ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / K::WN, wn = wid % K::WN;
     const int half = lane >> 5, l32 = lane & 31;
@@ -933,7 +939,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const unsigned long long mc_t1 = __builtin_readcyclecounter();
 #endif
     modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp,
-                                                                                                F16 ? row_unscale : nullptr, xus);
+                                                                                                F16 ? row_unscale : nullptr, xus, (TEAMS == 2) ? tid : -1, wg_scratch);
 #ifdef IDE3D_MC_TRACE
     if (blockIdx.x == 100 && (threadIdx.x == 0 || threadIdx.x == 256)) {          // wave 0 (and wave 4 of an 8-wave workgroup, at [16..])
         const int o = threadIdx.x ? 16 : 0;
@@ -1143,6 +1149,30 @@ modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float
     __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
     const BlockId b = decode_block(g);
     modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
+}
+
+// Two 4-wave teams per workgroup (exclusive residency without giving up the second wave per SIMD for the forms whose tile is too small
+// for eight waves: the 4 x 16-position transposed tiles of the 4^2 .. 32^2 layers).  Team t takes output-channel block 2 k + t of the same
+// (tile, image, K split): same geometry, same number of stages, so the workgroup barriers inside the tile code line up; each team has its
+// own LDS and its own thread numbering.  A team alone on a CU has nothing to overlap its staging with (round 4: 247 vs 183 us at 512 ->
+// 512 in@32 when two workgroups shared a CU); two teams in lock-step overlap less than two free-running workgroups did, but more than none.
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int F16>
+__global__ void __launch_bounds__(512, 2)
+modconv_split_teams_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
+    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, 4>;
+    static_assert(2 * K::LDS_BYTES <= 160 * 1024, "both teams' LDS must fit");
+    asm volatile("" ::: "v255");                       // 8 waves x 256 registers: the workgroup owns its CU's register files
+    __shared__ __attribute__((aligned(16))) unsigned char sp_smem[2 * K::LDS_BYTES];
+    const int team = (int)(threadIdx.x >> 8);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mpairs = g.mblocks >> 1;
+    BlockId b;
+    b.mb = 2 * (bid % mpairs) + team; bid /= mpairs;
+    b.tile = bid % g.tile_base[4]; bid /= g.tile_base[4];
+    b.grp = bid % g.img_groups; bid /= g.img_groups;
+    b.split = bid;
+    modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, 4, F16, 2>(p, wp, partial, g, sp_smem + team * K::LDS_BYTES, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale,
+                                                              reinterpret_cast<float*>(sp_smem));
 }
 
 // reduce split-K partials + epilogue
@@ -1377,7 +1407,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 const int64_t b8 = (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n, b16 = (int64_t)pl.mblocks * cdiv(p.h + 1, 16) * cdiv(p.w_ + 1, 16) * p.n;
                 if (pl.big == 1) pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
                 else if (b16 >= 2 * kNumCU) pl.tile = 7;
-                else if (p.h <= 16 && p.w_ <= 16) pl.tile = 6;       // 4^2 .. 16^2 maps (split-K): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves: 115 / 47 / 31)
+                else if (p.h <= 16 && p.w_ <= 16 && (pl.mblocks & 1)) pl.tile = 6;       // 4^2 .. 16^2 maps with an odd block count (no team pairs): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves alone on a CU: 115 / 47 / 31; two 4-wave teams: 92 / 45 / 24)
             }
         }
         if (pl.mode == MODE_CONV3) {
@@ -1459,7 +1489,18 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     // 8-wave forms (two of this workgroup's waves per SIMD: exclusive residency without giving up the second wave): IDE3D_SP_W8 bit 0 =
     // 3x3 on 8 x 16 pixels, bit 1 = all-class transposed 3x3 (8 x 16 positions at 128 rows, 16 x 16 at 64 rows)
     static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
-    if (pl.tile == 4) { if constexpr (MODE == MODE_TCONV3A) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru); }
+    if (pl.tile == 4) {
+        if constexpr (MODE == MODE_TCONV3A) {
+            static const bool no_teams = getenv("IDE3D_SP_NO_TEAMS") != nullptr;
+            if constexpr (BIG == 2) {          // 64-row blocks, even block count: two teams per workgroup (128-row blocks: LDS does not fit twice in bf16x6, and in f16x3 the teams measured 233 vs 217 us at 512 -> 256 in@64)
+                if (kSpExclusive && !no_teams && (g.mblocks & 1) == 0) {
+                    hipLaunchKernelGGL((modconv_split_teams_kernel<MODE, BIG, 4, PARTS, 2, F16>), dim3(nblocks / 2), dim3(512), 0, st, p, wu, partial, g, ru);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        }
+    }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr && !kSpExclusive;
