@@ -275,8 +275,41 @@ def _check(rc, what):
         raise RuntimeError(f'{what} failed (code {rc}): {msg}')
 
 
+# Host cost per launch matters for the drop-in loop shape (batch 1, eager: ~75 launches of 10-40 us of GPU work each; bench.py
+# `dropin_eager_b1`): the raw stream handle comes from torch's C entry point (no `Stream` object), and the device guard is a no-op when the
+# tensor's device is already current (the common single-GPU case).
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _stream_handle(device):
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_stream_handle(t.device))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _dev_guard(device):
+    """`with _dev_guard(t.device):` does what `with torch.cuda.device(t.device):` does, minus the context switch when that device is current."""
+    if device is None:
+        return _NO_GUARD
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
 
 
 # ---- who owns a launch's scratch memory ------------------------------------------------------------------------------------------
@@ -318,7 +351,7 @@ class workspace_scope:
 def _ws_domain(device):
     """Key component that separates workspaces of concurrent launch sequences: the owner of the active scope, else the current stream."""
     dom = getattr(_scope, 'domain', None)
-    return dom if dom is not None else ('stream', torch.cuda.current_stream(device).cuda_stream)
+    return dom if dom is not None else ('stream', _stream_handle(device))
 
 
 def _ptr(t):
@@ -366,7 +399,7 @@ class BiasActPlugin:
         if x.numel() == 0:
             return y
         step_b = x.stride(dim) if b.numel() else 1
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             rc = load().ide3d_bias_act(_ptr(x), _ptr(b), _ptr(xref), _ptr(yref), _ptr(dy), _ptr(y),
                                        _DTYPE_CODE[x.dtype], int(grad), int(act), float(alpha), float(gain), float(clamp),
                                        x.numel(), max(b.numel(), 1), int(step_b), _stream(x))
@@ -421,7 +454,7 @@ class Upfirdn2dPlugin:
         p.flip, p.gain = int(bool(flip)), float(gain)
         p.x_row_floats = _row_floats_readable(x)
         plain = add is None and noise is None and act is None and y_amax is None
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             if plain:
                 rc = load().ide3d_upfirdn2d(ctypes.byref(p), _stream(x))
             else:
@@ -519,7 +552,7 @@ class FilteredLReluPlugin:
         p.sign_mode = 1 if write_signs else (2 if read_signs else 0)
         p.flip = int(bool(flip_filters))
         p.gain, p.slope, p.clamp = float(gain), float(slope), float(min(clamp, 3.0e38))
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             rc = load().ide3d_filtered_lrelu(ctypes.byref(p), _stream(x))
         if rc == -2:     # IDE3D_ENOKERNEL: same contract as the reference's return_code = -1
             return torch.empty([0], device=x.device), torch.empty([0], device=x.device), -1
@@ -546,7 +579,7 @@ class FilteredLReluPlugin:
             _require(s.ndim == 4, 'signs must be rank 4')
             _require(s.shape[0] == n and s.shape[1] == c, 'signs must have same batch & channels as x')
         s_w, s_h = ((s.shape[3] << 2), s.shape[2]) if (read_signs or write_signs) else (0, 0)
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             rc = load().ide3d_filtered_lrelu_act(
                 _ptr(x), _ptr(s) if (read_signs or write_signs) else ctypes.c_void_p(0), _DTYPE_CODE[x.dtype],
                 n, c, h, w, ctypes.byref(_i64x4(x.stride())), s_w, s_h, sx, sy,
@@ -581,12 +614,12 @@ class TriplanePlugin:
         if ray_grid is not None:
             rh, rw, steps = (int(v) for v in ray_grid)
             _require(rh * rw * steps == m, 'ray_grid does not match the number of samples')
-            with torch.cuda.device(planes.device):
+            with _dev_guard(planes.device):
                 rc = load().ide3d_triplane_sample_rays(_ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
                                                        _ptr(coords), m, _ptr(out), rh, rw, steps, _stream(planes))
             _check(rc, 'triplane_sample_rays')
             return out
-        with torch.cuda.device(planes.device):
+        with _dev_guard(planes.device):
             rc = load().ide3d_triplane_sample(_ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
                                               _ptr(coords), m, _ptr(out), _stream(planes))
         _check(rc, 'triplane_sample')
@@ -598,7 +631,7 @@ class TriplanePlugin:
         _require(coords.is_cuda and coords.dtype == torch.float32, 'coords must be float32 on a CUDA device')
         taps = torch.empty([coords.shape[0], 3, 3], dtype=torch.int32, device=coords.device)
         if coords.shape[0]:
-            with torch.cuda.device(coords.device):
+            with _dev_guard(coords.device):
                 rc = load().ide3d_triplane_taps(H, W, _ptr(coords), coords.shape[0], _ptr(taps), _stream(coords))
             _check(rc, 'triplane_taps')
         return taps
@@ -613,7 +646,7 @@ class TriplanePlugin:
         grad_planes = torch.zeros_like(planes)
         grad_coords = torch.zeros_like(coords) if need_coord_grad else None
         if m:
-            with torch.cuda.device(planes.device):
+            with _dev_guard(planes.device):
                 rc = load().ide3d_triplane_sample_backward(
                     _ptr(grad_out), _ptr(planes), ctypes.byref(_i64x4(planes.stride())), n, C, H, W,
                     _ptr(coords), m, _ptr(grad_planes), ctypes.byref(_i64x4(grad_planes.stride())),
@@ -637,7 +670,7 @@ class VolumeRenderPlugin:
         rgb = torch.empty([rays, ch], dtype=torch.float32, device=dev)
         depth = torch.empty([rays], dtype=torch.float32, device=dev)
         weights = torch.empty([rays, steps], dtype=torch.float32, device=dev) if want_weights else None
-        with torch.cuda.device(dev):
+        with _dev_guard(dev):
             rc = load().ide3d_composite(_ptr(rgb_sigma), _ptr(z_vals), _ptr(dir_norm), _ptr(noise), rays, steps, ch,
                                         int(clamp_mode), int(bool(last_back)), int(bool(white_back)), float(max_depth or 0.0),
                                         int(fill_mode), _ptr(rgb), _ptr(depth), _ptr(weights), _stream(rgb_sigma))
@@ -656,7 +689,7 @@ class VolumeRenderPlugin:
         bins, weights, u = bins.contiguous(), weights.contiguous(), u.contiguous()
         n_imp = u.shape[-1]
         out = torch.empty([rays, n_imp], dtype=torch.float32, device=weights.device)
-        with torch.cuda.device(weights.device):
+        with _dev_guard(weights.device):
             rc = load().ide3d_sample_pdf(_ptr(bins), _ptr(weights), _ptr(u), 0 if u.ndim == 1 else n_imp, rays, k, n_imp,
                                          float(eps), _ptr(out), _stream(weights))
         _check(rc, 'sample_pdf')
@@ -715,7 +748,7 @@ class VolumeRenderPlugin:
         depth = torch.empty([n, R], dtype=torch.float32, device=dev)
         wsum = torch.empty([n, R], dtype=torch.float32, device=dev)
         p.out_feat, p.out_depth, p.out_wsum = feat.data_ptr(), depth.data_ptr(), wsum.data_ptr()
-        with torch.cuda.device(dev):
+        with _dev_guard(dev):
             rc = load().ide3d_render_rays(ctypes.byref(p), _stream(tex_planes))
         if rc == -2:        # IDE3D_ENOKERNEL: configuration not covered by the fused kernel
             return None
@@ -735,7 +768,7 @@ class VolumeRenderPlugin:
         out = None if sigma_only else torch.empty([n * m, width], dtype=torch.float32, device=dev)
         sig = torch.empty([n * m], dtype=torch.float32, device=dev) if sigma_only else None
         if m:
-            with torch.cuda.device(dev):
+            with _dev_guard(dev):
                 rc = load().ide3d_sample_voxel(ctypes.byref(p), _ptr(pts), m, _ptr(out), _ptr(sig), int(sigma_only), _stream(pts))
             if rc == -2:
                 return None
@@ -758,7 +791,7 @@ class VolumeRenderPlugin:
         _require(device.type == 'cuda', 'lattice_points: CUDA device required')
         pts = torch.empty([count, 3], dtype=torch.float32, device=device)
         lat = VolumeRenderPlugin._lattice(n, voxel_size, corner, scale)
-        with torch.cuda.device(device):
+        with _dev_guard(device):
             rc = load().ide3d_lattice_points(ctypes.byref(lat), int(first), int(count), _ptr(pts), _stream(pts))
         _check(rc, 'lattice_points')
         return pts
@@ -771,7 +804,7 @@ class VolumeRenderPlugin:
         lat = VolumeRenderPlugin._lattice(n, voxel_size, corner, scale)
         sig = torch.empty([p.n * int(count)], dtype=torch.float32, device=tex_planes.device)
         if count:
-            with torch.cuda.device(tex_planes.device):
+            with _dev_guard(tex_planes.device):
                 rc = load().ide3d_density_lattice(ctypes.byref(p), ctypes.byref(lat), int(first), int(count), _ptr(sig), _stream(tex_planes))
             if rc == -2:
                 return None
@@ -851,7 +884,7 @@ class ModconvPlugin:
                 setattr(p, name, t.data_ptr())
         p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
         p.y_pitch = pitch if pitch != ow else 0
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             rc = lib.ide3d_modconv2d(ctypes.byref(p), _stream(x))
         _check(rc, 'modconv2d')
         ent[1], ent[2] = (None, None) if per_image else (w._version, weakref.ref(w))
@@ -899,7 +932,7 @@ class StylePlugin:
             _require(wsq_t.is_contiguous() and wsq_t.shape[0] == cin, 'style_demod: wsq_t must be contiguous [cin, cout]')
             cout = wsq_t.shape[1]
             dcoefs = torch.empty([n, cout], dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _dev_guard(w.device):
             rc = load().ide3d_style_demod(_ptr(w), w.stride(0), _ptr(affine_w), _ptr(affine_b), _ptr(wsq_t), n, cin, cout, wdim,
                                           float(affine_gain), float(bias_gain), _ptr(styles), _ptr(dcoefs), _stream(w))
         _check(rc, 'style_demod')
@@ -916,7 +949,7 @@ class StylePlugin:
             _require(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'fold_heads: contiguous float32 CUDA tensors required')
             _require(t.device == w.device, 'fold_heads: all tensors must reside on the same device as w')
         out = torch.empty([n, cout0 + cout1, cin, 1, 1], dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _dev_guard(w.device):
             rc = load().ide3d_fold_heads(_ptr(w), w.stride(0), n, cin, wdim, float(affine_gain), _ptr(a0), _ptr(b0), _ptr(w0), cout0, float(gain0),
                                          _ptr(a1), _ptr(b1), _ptr(w1), cout1, float(gain1), _ptr(out), _stream(w))
         _check(rc, 'fold_heads')
@@ -961,7 +994,7 @@ class StylePlugin:
             j.styles, j.dcoefs = styles.data_ptr(), (dco.data_ptr() if dco is not None else None)
             outs.append((styles, dco))
         lib = load()
-        with torch.cuda.device(dev):
+        with _dev_guard(dev):
             for k0 in range(0, len(jobs), STYLE_BATCH_MAX):
                 cnt = min(STYLE_BATCH_MAX, len(jobs) - k0)
                 rc = lib.ide3d_style_demod_batch(ctypes.cast(ctypes.byref(arr, k0 * ctypes.sizeof(_StyleJob)), ctypes.POINTER(_StyleJob)),
@@ -998,7 +1031,7 @@ class StylePlugin:
             j.out = out.data_ptr()
             outs.append(out)
         lib = load()
-        with torch.cuda.device(dev):
+        with _dev_guard(dev):
             for k0 in range(0, len(jobs), STYLE_BATCH_MAX):
                 cnt = min(STYLE_BATCH_MAX, len(jobs) - k0)
                 rc = lib.ide3d_fold_heads_batch(ctypes.cast(ctypes.byref(arr, k0 * ctypes.sizeof(_FoldJob)), ctypes.POINTER(_FoldJob)),
@@ -1019,7 +1052,7 @@ class FramePlugin:
             out = torch.empty([n, H, 2 * W, 3], dtype=torch.uint8, device=img.device)
         _require(out.dtype == torch.uint8 and tuple(out.shape) == (n, H, 2 * W, 3) and out.is_contiguous() and out.device == img.device,
                  'frame_u8: out must be a contiguous uint8 [N, H, 2W, 3] tensor on the image device')
-        with torch.cuda.device(img.device):
+        with _dev_guard(img.device):
             rc = load().ide3d_frame_u8(_ptr(img), _ptr(seg), _ptr(palette.contiguous()), n, classes, H, W, _ptr(out), _stream(img))
         _check(rc, 'frame_u8')
         return out
@@ -1036,7 +1069,7 @@ class MappingPlugin:
         if not (1 <= n <= MappingPlugin.MAX_N and 0 < k0 <= MappingPlugin.MAX_WIDTH and k0 % 4 == 0 and 1 <= len(widths) <= MappingPlugin.MAX_LAYERS
                 and all(0 < w <= MappingPlugin.MAX_WIDTH and w % 4 == 0 for w in widths)):
             return False
-        with torch.cuda.device(device):                              # None: no-op guard
+        with _dev_guard(device):                              # None: no-op guard
             return bool(load().ide3d_mapping_supported())            # the kernel's grid barrier needs its 64 workgroups co-resident
 
     @staticmethod
@@ -1076,7 +1109,7 @@ class MappingPlugin:
         p.embed_weight_gain, p.embed_bias_gain, p.lr_multiplier = float(embed_wgain), float(embed_bgain), float(lr_multiplier)
         p.alpha, p.act_gain, p.truncation_psi = float(alpha), float(act_gain), float(psi)
         p.truncation_cutoff = -1 if cutoff is None else int(cutoff)
-        with torch.cuda.device(dev):
+        with _dev_guard(dev):
             rc = lib.ide3d_mapping(ctypes.byref(p), _stream(z))
         _check(rc, 'mapping')
         return out
@@ -1092,7 +1125,7 @@ class ResamplePlugin:
         _require(tuple(add.shape) == (n, c, 2 * h, 2 * w), 'skip_upsample_add_cl: add must be [n, c, 2h, 2w]')
         _require(c % 4 == 0, 'skip_upsample_add_cl: channel count must be a multiple of 4')
         out = torch.empty([n, c, 2 * h, 2 * w], dtype=torch.float32, device=lo.device, memory_format=torch.channels_last)
-        with torch.cuda.device(lo.device):
+        with _dev_guard(lo.device):
             rc = load().ide3d_skip_upsample_add_cl(_ptr(lo), ctypes.byref(_i64x4(lo.stride())), _ptr(add), ctypes.byref(_i64x4(add.stride())),
                                                    n, c, h, w, _ptr(out), _stream(lo))
         _check(rc, 'skip_upsample_add_cl')
@@ -1109,7 +1142,7 @@ class ResamplePlugin:
         dst = (ctypes.c_void_p * 3)(*([o.data_ptr() for o in outs] + [0] * (3 - len(outs))))
         beg = (ctypes.c_int32 * 3)(*([int(b) for b, _c in ranges] + [0] * (3 - len(outs))))
         cnt = (ctypes.c_int32 * 3)(*([int(c_) for _b, c_ in ranges] + [0] * (3 - len(outs))))
-        with torch.cuda.device(x.device):
+        with _dev_guard(x.device):
             rc = load().ide3d_bilinear_up2_split(_ptr(x), n, c, h, w, ctypes.byref(dst), ctypes.byref(beg), ctypes.byref(cnt), _stream(x))
         _check(rc, 'bilinear_up2_split')
         return outs
