@@ -125,6 +125,41 @@ def test_upfirdn2d_tile_kernels(gpu_device, shape, kw, dtype, tol):
     assert_close(y.float(), ref, rtol=tol, atol=tol, what=f'{shape} {kw}')
 
 
+def test_upfirdn2d_views_never_read_past_their_storage(gpu_device):
+    """the 16-byte staging path of the tile kernels reads whole aligned quads of a row, i.e. up to round_up(in_w, 4) - 1.  It
+    may only run when that much of EVERY row is readable (`x_row_floats`, ABI 5): W-offset views whose last row ends the storage, H-strided
+    views with an odd row count and widths that are not multiples of 4 take the scalar staging.  Results against the oracle in every case;
+    the promise the binding makes is checked directly as well."""
+    from torch_utils import hip_plugin
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(8)
+    f = torch.tensor([[1., 2., 3., 4.], [0.5, 3., 3., 1.], [2., 3., 5., 1.], [1., 3., 3., 7.]]) / 40
+    base = torch.randn(2, 3, 37, 52, generator=g).to(gpu_device)          # the storage ends with the last row of the last plane
+    cases = {
+        'dense, in_w % 4 == 0': base,
+        'W-offset view t[..., 4:]': base[..., 4:],
+        'W-offset view t[..., 3:] (unaligned rows)': base[..., 3:],
+        'narrow view t[..., :45] (in_w % 4 = 1, padding readable inside the row)': base[..., :45],
+        'H-strided view, odd row count': base[:, :, ::2],
+        'H-strided view of a 50-wide tensor (in_w % 4 = 2)': torch.randn(1, 2, 33, 50, generator=g).to(gpu_device)[:, :, ::2],
+    }
+    for name, x in cases.items():
+        n_readable = hip_plugin._row_floats_readable(x)
+        last_row = x.storage_offset() + sum((x.shape[i] - 1) * x.stride(i) for i in range(3))
+        total = x.untyped_storage().nbytes() // 4
+        assert n_readable == total - last_row and n_readable >= x.shape[3], name
+        for kw in (dict(up=1, padding=[1, 1, 1, 1], gain=4), dict(up=1, padding=[2, 1, 2, 1], flip_filter=True)):
+            y = upfirdn2d.upfirdn2d(x, f.to(gpu_device), **kw)
+            ref = fast_ops.upfirdn2d(x.cpu().contiguous(), f, **kw)
+            assert_close(y, ref, rtol=1e-5, atol=1e-5, what=f'{name} {kw}')
+    # the padded-row output of the transposed convolution (the case the fast staging exists for): rows of 65 floats inside a pitch of 68
+    pad = torch.randn(2, 4, 65, 68, generator=g).to(gpu_device)
+    view = pad[..., :65]
+    assert hip_plugin._row_floats_readable(view) >= 68
+    y = upfirdn2d.upfirdn2d(view, f.to(gpu_device), up=1, padding=[1, 1, 1, 1], gain=4)
+    assert_close(y, fast_ops.upfirdn2d(view.cpu().contiguous(), f, up=1, padding=[1, 1, 1, 1], gain=4), rtol=1e-5, atol=1e-5, what='padded rows')
+
+
 def test_upfirdn2d_channels_last_and_f64(gpu_device):
     from torch_utils.ops import upfirdn2d
     g = torch.Generator().manual_seed(4)

@@ -450,3 +450,17 @@ print('LAZY_OK')
     res = subprocess.run([sys.executable, '-c', code, os.path.join(ROOT, 'ide-3d_amd'), str(tmp_path / 'fake_ref')],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and 'LAZY_OK' in res.stdout, res.stdout[-3000:]
+
+
+def test_row_floats_readable_is_the_distance_to_the_end_of_storage():
+    """`ide3d_upfirdn2d_params.x_row_floats` (ABI 5): what the binding promises the kernel may read from the start of the row that starts
+    last in storage — the 16-byte staging path is only taken when round_up(in_w, 4) fits into it."""
+    from torch_utils import hip_plugin
+    base = torch.zeros(2, 3, 9, 20)
+    assert hip_plugin._row_floats_readable(base) == 20                       # dense: exactly one row
+    assert hip_plugin._row_floats_readable(base[..., 4:]) == 16              # W-offset view: the last row ends the storage
+    assert hip_plugin._row_floats_readable(base[..., :13]) == 20             # narrow view: the rest of the row is readable
+    assert hip_plugin._row_floats_readable(base[:, :, ::2]) == 20            # H-strided, odd row count: last viewed row = last row
+    assert hip_plugin._row_floats_readable(base[:, :, :8:2]) == 20 + 2 * 20  # H-strided view ending two rows earlier
+    assert hip_plugin._row_floats_readable(base.flip(3)) == 0 if any(s <= 0 for s in base.flip(3).stride()) else True
+    assert hip_plugin._row_floats_readable(torch.zeros(4, 5)) == 0           # not rank 4: no promise
