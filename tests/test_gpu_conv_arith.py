@@ -503,7 +503,7 @@ def test_foreign_packed_fp32_victim_beside_every_matrix_loop(gpu_device):
     for cin, cout, res, mode in ((128, 128, 256, 0), (64, 64, 512, 0), (512, 512, 64, 0), (256, 128, 128, 2), (128, 64, 256, 2), (512, 256, 64, 2), (512, 512, 16, 2)):
         x = rn(4, cin, res, res); wt = rn(cout, cin, 3, 3); s = rn(4, cin) + 1; d = torch.rand(4, cout, generator=g).to(dev)
         xam = _finite_amax(x)
-        for arith, code in (('bf16x6', 6), ('f16x3', 16), ('bf16x3', 3)):
+        for arith, code in (('bf16x6', 6), ('f16x3', 16), ('bf16x3', 3), ('fp32', 1)):      # fp32: the LDS-fed v_mfma_f32_32x32x2_f32 loop, which shares SIMDs
             neighbours[f'conv {cin}->{cout} @{res} mode {mode} [{arith}]'] = \
                 (lambda x=x, wt=wt, s=s, d=d, xam=xam, mode=mode, code=code: _mc()(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=mode, arith=code, x_amax=xam))
     for cin, cout, res in ((128, 192, 256), (64, 22, 512)):
@@ -525,6 +525,11 @@ def test_foreign_packed_fp32_victim_beside_every_matrix_loop(gpu_device):
                 bad = changed_launches(fn)
             record[name] = bad
         assert hip_plugin.CALLS.get('render_rays', 0) > before
+        # the fp32 forms of the ray-marcher (v_mfma_f32_16x16x4_f32 fed from LDS, two 4-wave workgroups per CU: SIMDs are shared)
+        hip_plugin.conv_arithmetic('fp32')
+        with torch.no_grad():
+            R(tex, geo, cam, jitter=False)
+            record['render_rays [fp32 MLPs]'] = changed_launches(lambda: R(tex, geo, cam, jitter=False))
     finally:
         hip_plugin.conv_arithmetic('default')
     import json, os
