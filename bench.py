@@ -313,8 +313,28 @@ def dropin_eager_b1(G, device, palette, images=24, warm=4):
         one(s)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {'frames_per_s': round(images / dt, 1), 'ms_per_image': round(dt / images * 1e3, 3), 'images': images,
-            'what': 'gen_images.py loop shape: batch 1, eager launches, library-default arithmetic'}
+    rec = {'frames_per_s': round(images / dt, 1), 'ms_per_image': round(dt / images * 1e3, 3), 'images': images,
+           'what': 'gen_images.py loop shape: batch 1, eager launches, library-default arithmetic'}
+    # the same loop with the two calls wrapped in a batch-1 hipGraph (`triplane.GraphedRenderer(G, 1, device)`: the one-line change a caller
+    # of gen_images.py can make): the eager loop is bound by its ~75 host-side launches per image, the replay by the GPU
+    run = triplane.GraphedRenderer(G, 1, device, static_labels=True)
+
+    def one_graphed(seed):
+        z = torch.from_numpy(np.random.RandomState(seed).randn(1, G.z_dim)).float().pin_memory()
+        img, seg = run(z, cond, cam)
+        with torch.no_grad():
+            return dr.frames_u8(img, seg, palette)
+
+    for s in range(warm):
+        one_graphed(20_000 + s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(images):
+        one_graphed(s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec['graphed_b1_frames_per_s'] = round(images / dt, 1)
+    return rec
 
 
 ARITH_DTYPE_SHORT = {'fp32': 'f32', 'f16x3': 'f32 (3x3 convs: f16x3 split, f32 accumulate)', 'bf16x6': 'f32 (3x3 convs + MLPs: fp32 operands as 3 bf16 pieces, 6 products, f32 accumulate)',
