@@ -888,11 +888,22 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             // Software pipeline over (tap, piece) groups: the A and B pieces q of tap kx are one group of MTW + NTW 16-byte reads;
             // group s + 1 is in flight while the products that group s completes - (qa, qb) with max(qa, qb) = q and
             // qa + qb < PARTS - multiply.  At most two groups (<= 12 reads) are outstanding: lgkmcnt is a 4-bit counter.
-            u32x4 av[2][K::MTW][PARTS], bv[2][K::NTW][PARTS];
+            // AHEAD groups in flight (compile-time knob IDE3D_SP_AHEAD; default 1 = the round-2 pipeline).  Round 4 measured 2 (bf16x6; f16x3 with
+            // a third tap buffer): 338 vs 330 us at 128 -> 128 @256, 255 vs 251 at the transposed 256 -> 128, 218 vs 211 in f16x3 - with two
+            // waves per SIMD the LDS latency is already covered, more reads in flight only delay the first product.  The operand registers of a tap are reused by the tap
+            // two taps later (NBUF = 2) or three (NBUF = 3): group s + AHEAD may only be issued once every product of the tap it overwrites
+            // has been ISSUED at least one group earlier, i.e. AHEAD <= (NBUF - 1) * PARTS - 1; and (AHEAD + 1) * GRP <= 15 reads outstanding.
             constexpr int GRP = K::MTW + K::NTW, NGRP = 3 * PARTS;
-            static_assert(2 * GRP <= 15, "lgkmcnt is a 4-bit counter");
+#ifndef IDE3D_SP_AHEAD
+#define IDE3D_SP_AHEAD 1
+#endif
+            constexpr int NBUF = (PARTS == 2 && IDE3D_SP_AHEAD > 1) ? 3 : 2;
+            constexpr int AHEAD_CAP = 15 / GRP - 1, AHEAD_SAFE = (NBUF - 1) * PARTS - 1;
+            constexpr int AHEAD = (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) < AHEAD_SAFE ? (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) : AHEAD_SAFE;
+            static_assert(AHEAD >= 1 && (AHEAD + 1) * GRP <= 15, "lgkmcnt is a 4-bit counter");
+            u32x4 av[NBUF][K::MTW][PARTS], bv[NBUF][K::NTW][PARTS];
             auto issue = [&](auto ss) {
-                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX & 1, T = KY * 3 + KX;
+                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, T = KY * 3 + KX;
                 static_for<K::MTW>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
                     av[B][I][Q] = lds_read128_async<(((KX * PARTS + Q) * 2) * K::BM + I * 32) * 16>(a_base);
@@ -902,11 +913,12 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
                     bv[B][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
                 });
             };
-            issue(std::integral_constant<int, 0>{});
+            static_for<AHEAD>([&](auto ss) { issue(ss); });
             static_for<NGRP>([&](auto ss) {
-                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX & 1, QC = tap_class<MODE>(KY * 3 + KX);
-                if constexpr (S + 1 < NGRP) issue(std::integral_constant<int, S + 1>{});
-                lds_wait128<(S + 1 < NGRP) ? GRP : 0>(av[B][0][Q]);
+                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, QC = tap_class<MODE>(KY * 3 + KX);
+                if constexpr (S + AHEAD < NGRP) issue(std::integral_constant<int, S + AHEAD>{});
+                constexpr int BEHIND = (NGRP - 1 - S < AHEAD) ? NGRP - 1 - S : AHEAD;            // groups issued after group S
+                lds_wait128<BEHIND * GRP>(av[B][0][Q]);
 #pragma unroll
                 for (int i = 0; i < K::MTW; ++i) lds_pin128(av[B][i][Q]);
 #pragma unroll
