@@ -1106,6 +1106,139 @@ head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchu
     modconv_finish<MODE_CONV1, 1, 1, K::BN, K::NWV, 1, MT, 1, K::ROWS, S_UNITS * 4>(pf, nullptr, g, acc, reinterpret_cast<float*>(s_a), 0, n0, 0, tile * K::BN, 0, 0, 0, wid, l32);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Last output row / column of the transposed 3x3 convolution (round 4)
+// ------------------------------------------------------------------------------------------------
+// y = conv_transpose2d(x, w, stride 2) is (2h + 1) x (2w + 1): oy = 2 iy + ky.  The all-class kernels tile the (h + 1) x (w + 1) grid of
+// positions g (outputs 2g + class), and the "+ 1" row / column is pure tile quantisation at the benchmark's power-of-two maps: 129 x 129
+// positions in 8 x 16 tiles = 612 workgroups = 2.4 rounds of one workgroup per CU — three rounds — where 128 x 128 = 512 = two (same for
+// 257^2 in 16 x 16: 1156 vs 1024, 65^2 in 4 x 16: 680 vs 512, 33^2: 864 vs 512).  That extra position row / column only produces output
+// row 2h (from input row h - 1, ky = 2) and column 2w (input column w - 1, kx = 2): a 1-D transposed convolution, 0.3 % of the layer's
+// work.  In `strip` plans the main kernel runs on the h x w grid and this kernel fills row 2h and column 2w with plain fp32 FMAs (exact
+// products, one thread per output position x 8 output channels; styles / demodulation like the main kernel; `y_amax` raised).
+constexpr int STRIP_CO = 8, STRIP_WAVES = 16;     // 16 waves: the input channels of a workgroup in 16 interleaved slices (8 waves: 244 us at 512 -> 256 in@64)
+// strip weights of a layer, packed once per weight version: ws[ci][t][co], t = 0..2: w[co, ci, ky = 2, kx = t] (row), t = 3..5: w[co, ci, ky = t - 3, kx = 2]
+// (column); co padded to a multiple of STRIP_CO
+__global__ void __launch_bounds__(256)
+tconv_strip_pack_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, float* __restrict__ ws) {
+    const int64_t total = (int64_t)cin * 6 * cout_pad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cout_pad); const int64_t r = i / cout_pad;
+        const int t = (int)(r % 6), ci = (int)(r / 6);
+        const int tap = t < 3 ? 6 + t : (t - 3) * 3 + 2;
+        ws[i] = co < cout ? w[((int64_t)co * cin + ci) * 9 + tap] : 0.f;
+    }
+}
+// The strip's inputs — row h - 1 and column w - 1 of every input channel — gathered into xs[n][ci][w + h] first.  Read in place they sit at
+// the same offset of every power-of-two sized channel plane, i.e. in ONE L2 channel, and every output-channel block of the strip kernel
+// reads all of them again: 79 us per launch at 512 -> 256 in@64 against 25 us with the loads removed.  Gathered, consecutive channels are
+// (w + h) * 4 bytes apart and spread over the channels; the gather itself touches each line once.
+__global__ void __launch_bounds__(256)
+tconv_strip_gather_kernel(const float* __restrict__ x, int rows, int h, int w_, float* __restrict__ xs) {
+    const int len = w_ + h;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * len; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / len; const int e = (int)(i - r * len);
+        xs[i] = e < w_ ? x[r * h * w_ + (int64_t)(h - 1) * w_ + e] : x[r * h * w_ + (int64_t)(e - w_) * w_ + (w_ - 1)];
+    }
+}
+// One workgroup = 64 strip positions of ONE kind — row / column x even / odd position, so that which taps contribute is uniform: even
+// positions t = 2a take x[a] * w(tap 0) + x[a - 1] * w(tap 2), odd ones t = 2a + 1 take x[a] * w(tap 1) — x STRIP_CO output channels of one
+// image; wave q sums the input channels ci = q, q + 8, ... (lane = position), the eight partial sums meet in LDS.
+__global__ void __launch_bounds__(64 * STRIP_WAVES, 4)      // <= 128 registers
+tconv_strip_kernel(ide3d_modconv_params p, const float* __restrict__ ws, const float* __restrict__ xs, int cout_pad, int oh, int ow, int64_t pitch,
+                   int nb_re, int nb_ro, int nb_ce) {
+    __shared__ float s_red[STRIP_WAVES][STRIP_CO][64];
+    __shared__ float s_am[STRIP_WAVES];
+    const int h = p.h, w_ = p.w_;
+    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // block kind (uniform): 0 row even, 1 row odd, 2 column even, 3 column odd
+    int b = (int)blockIdx.x, kind = 0;
+    if (b >= nb_re) { b -= nb_re; kind = 1; if (b >= nb_ro) { b -= nb_ro; kind = 2; if (b >= nb_ce) { b -= nb_ce; kind = 3; } } }
+    const bool is_row = kind < 2, odd = kind & 1;
+    const int a = b * 64 + lane;
+    const int t = 2 * a + (odd ? 1 : 0);                          // ox on the row / oy on the column
+    const bool live = t < (is_row ? ow : oh - 1);
+    const int co0 = (int)blockIdx.y * STRIP_CO, n = (int)blockIdx.z;
+    const int len = is_row ? w_ : h;
+    const bool ok_a = live && a < len, ok_b = live && !odd && a >= 1;
+    const int64_t xs_pitch = (int64_t)w_ + h;                    // gathered strip inputs: [ci][row h - 1 (w floats) | column w - 1 (h floats)]
+    const float* __restrict__ xn = xs + (int64_t)n * p.cin * xs_pitch;
+    const int64_t off_a = (is_row ? 0 : w_) + min(a, len - 1), off_b = (is_row ? 0 : w_) + min(max(a - 1, 0), len - 1);     // valid for every lane: unconditional loads
+    const float* __restrict__ wt = ws + (is_row ? 0 : 3) * (int64_t)cout_pad + co0;      // + (ci * 6 + tap) * cout_pad
+    // The (ci, tap, co) weights are wave-uniform, and hipcc turns uniform global loads of this pattern into per-lane dwordx4 loads (30 per
+    // unrolled iteration: 133 us per launch in the first version).  Each wave therefore fetches the 8 x 24 weights of ITS input channels of a
+    // chunk with three coalesced loads per lane, parks them in a wave-private LDS slice and reads them back as broadcasts: no workgroup
+    // barrier inside the K loop, and every load of a chunk — samples, styles, weights — is in flight together.
+    constexpr int STRIP_CH = 8 * STRIP_WAVES, PER_WAVE = STRIP_CH / STRIP_WAVES, WPC = 3 * STRIP_CO;      // 8 input channels per wave and chunk, 24 weights per input channel
+    static_assert(PER_WAVE * WPC == 3 * 64, "three weight loads per lane and chunk");
+    __shared__ __attribute__((aligned(16))) float s_wt[STRIP_WAVES][PER_WAVE * WPC];
+    float acc[STRIP_CO];
+#pragma unroll
+    for (int j = 0; j < STRIP_CO; ++j) acc[j] = 0.f;
+    // (a software pipeline over the chunks - the loads of chunk c + 1 in flight across the multiplications of chunk c - measured no better:
+    // 245 / 162 vs 242 / 151 us at 512 -> 256 in@64 / 512 -> 512 in@32)
+    for (int c0 = 0; c0 < p.cin; c0 += STRIP_CH) {
+        float xa[PER_WAVE], xb[PER_WAVE], scv[PER_WAVE], wreg[3];
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ci = min(c0 + q + k * STRIP_WAVES, p.cin - 1);
+            xa[k] = xn[(int64_t)ci * xs_pitch + off_a];
+            xb[k] = odd ? 0.f : xn[(int64_t)ci * xs_pitch + off_b];
+            scv[k] = p.styles ? p.styles[(int64_t)n * p.cin + ci] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = lane + 64 * r, k = e / WPC, rem = e - k * WPC, tp = rem / STRIP_CO, jj = rem - tp * STRIP_CO;
+            const int ci = c0 + q + k * STRIP_WAVES;
+            wreg[r] = (ci < p.cin) ? wt[((int64_t)ci * 6 + tp) * cout_pad + jj] : 0.f;          // zero beyond cin
+        }
+        __builtin_amdgcn_wave_barrier();                                      // (the previous chunk's reads of this slice are done: same wave, in order)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s_wt[q][lane + 64 * r] = wreg[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const float va = ok_a ? xa[k] * scv[k] : 0.f;
+            const float4* wv = reinterpret_cast<const float4*>(&s_wt[q][k * WPC]);       // broadcast reads: every lane the same address
+            if (odd) {
+                const float4 b0 = wv[2], b1 = wv[3];
+                const float w1[STRIP_CO] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < STRIP_CO; ++j) acc[j] = fmaf(va, w1[j], acc[j]);
+            } else {
+                const float vb = ok_b ? xb[k] * scv[k] : 0.f;
+                const float4 a0 = wv[0], a1 = wv[1], c0v = wv[4], c1v = wv[5];
+                const float w0[STRIP_CO] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float w2[STRIP_CO] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
+#pragma unroll
+                for (int j = 0; j < STRIP_CO; ++j) { acc[j] = fmaf(va, w0[j], acc[j]); acc[j] = fmaf(vb, w2[j], acc[j]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < STRIP_CO; ++j) s_red[q][j][lane] = acc[j];
+    __syncthreads();
+    float am = 0.f;
+    {
+        static_assert(STRIP_CO <= STRIP_WAVES, "wave q < STRIP_CO finishes output channel co0 + q");
+        float v = 0.f;
+        const int qc = min(q, STRIP_CO - 1);
+#pragma unroll
+        for (int k = 0; k < STRIP_WAVES; ++k) v += s_red[k][qc][lane];
+        const int co = co0 + q;
+        if (live && q < STRIP_CO && co < p.cout) {
+            v *= p.dcoefs ? p.dcoefs[(int64_t)n * p.cout + co] : 1.f;
+            const int oy = is_row ? oh - 1 : t, ox = is_row ? t : ow - 1;
+            p.y[((int64_t)n * p.cout + co) * ((int64_t)oh * pitch) + (int64_t)oy * pitch + ox] = v;
+            amax_acc(am, v);
+        }
+    }
+    if (p.y_amax) amax_raise_block(p.y_amax, n, am, s_am);
+}
+
 // ((split, img_group, tile), m-block) with m-block fastest (blocks that share an input patch are neighbours)
 struct BlockId { int mb, tile, grp, split; };
 __device__ __forceinline__ BlockId decode_block(const ConvGeom& g) {
@@ -1286,6 +1419,8 @@ struct ConvPlan {
     int bm, kc, taps, mblocks, cchunks, oh, ow;
     int parts;                       // 0: fp32 MFMA loop; 2 / 3: split loop with that many pieces per operand
     int f16;                         // split loop on fp16 pieces (f16x3: parts == 2) instead of bf16
+    int strip;                       // all-class transposed conv on the h x w class grid; output row 2h and column 2w by tconv_strip_kernel
+    int64_t strip_off, strip_floats; // packed strip weights [cin][6][cout_pad] inside the aux region (every all-class plan reserves them)
     int64_t packed_floats, aux_floats, partial_floats;      // aux: per-row scale + unscale of the f16x3 weights
     ConvGeom g;
 };
@@ -1361,7 +1496,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
     pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
-    pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0;
+    pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0;
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -1443,6 +1578,25 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
     }
     static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
+    if (pl.mode == MODE_TCONV3A) {                              // reserved whether or not this call's epilogue allows the strip plan (workspace sizing does not know)
+        pl.strip_off = pl.aux_floats;
+        pl.strip_floats = (int64_t)p.cin * 6 * (cdiv(p.cout, STRIP_CO) * STRIP_CO);
+        pl.aux_floats += pl.strip_floats + (int64_t)p.n * p.cin * (p.h + p.w_);          // + the gathered strip inputs xs[n][cin][w + h]
+    }
+    // Strip plan (tconv_strip_kernel): the all-class transposed convolution on the h x w grid when that saves tiles, the launch needs no split-K
+    // either way (the reduction kernel would finish the strip's unwritten partials) and the epilogue is the plain one of the up-sampling
+    // layers (demodulation only: noise / bias / activation follow the FIR).  IDE3D_MODCONV_NO_STRIP = the (h + 1) x (w + 1) grid everywhere.
+    pl.strip = 0;
+    if (pl.mode == MODE_TCONV3A && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP")) {
+        const int ph = PHv[pl.tile], pw = PWv[pl.tile];
+        const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
+        const int64_t groups = cdiv(p.n, TIv[pl.tile]);
+        auto splits = [&](int64_t tiles) { return (int64_t)pl.mblocks * tiles * groups < 512 && pl.cchunks >= 8; };
+        if (t_main < t_full && !splits(t_main) && !splits(t_full)) {
+            pl.strip = 1;
+            for (int c = 0; c < 4; ++c) { gh[c] = p.h; gw[c] = p.w_; }
+        }
+    }
     ConvGeom& g = pl.g;
     g.tile_base[0] = 0;
     for (int c = 0; c < 4; ++c) {
@@ -1646,6 +1800,21 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     if (pl.g.split_k > 1) {
         const int64_t per = (int64_t)p.n * p.cout * pl.oh * pl.ow;
         hipLaunchKernelGGL(modconv_epilogue_kernel, dim3(stream_grid((p.y_pitch <= 0 && ((pl.oh * pl.ow) & 3) == 0) ? per / 4 : per, 256)), dim3(256), 0, st, p, partial, pl.g.split_k, pl.oh, pl.ow);
+    }
+    if (pl.mode == MODE_TCONV3A && !p.weights_packed) {
+        // the strip weights are packed with the main ones, whether or not THIS call's epilogue allows the strip plan: `weights_packed` of a later
+        // call vouches for the whole workspace
+        hipLaunchKernelGGL(tconv_strip_pack_kernel, dim3(stream_grid(pl.strip_floats, 256)), dim3(256), 0, st, p.w, p.cout, p.cin, cdiv(p.cout, STRIP_CO) * STRIP_CO,
+                           wp + pl.packed_floats + pl.strip_off);
+    }
+    if (pl.strip) {
+        const int cout_pad = cdiv(p.cout, STRIP_CO) * STRIP_CO;
+        float* const wstrip = wp + pl.packed_floats + pl.strip_off;
+        const int nb_re = cdiv(p.w_ + 1, 64), nb_ro = cdiv(p.w_, 64), nb_ce = cdiv(p.h, 64), nb_co = cdiv(p.h, 64);
+        float* const xs = wstrip + pl.strip_floats;
+        hipLaunchKernelGGL(tconv_strip_gather_kernel, dim3(stream_grid((int64_t)p.n * p.cin * (p.h + p.w_), 256)), dim3(256), 0, st, p.x, p.n * p.cin, p.h, p.w_, xs);
+        hipLaunchKernelGGL(tconv_strip_kernel, dim3(nb_re + nb_ro + nb_ce + nb_co, cout_pad / STRIP_CO, p.n), dim3(64 * STRIP_WAVES), 0, st, p, wstrip, xs, cout_pad,
+                           pl.oh, pl.ow, (int64_t)(p.y_pitch > 0 ? p.y_pitch : pl.ow), nb_re, nb_ro, nb_ce);
     }
     IDE3D_CHECK_LAUNCH("modconv2d");
     return IDE3D_OK;

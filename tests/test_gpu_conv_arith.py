@@ -581,3 +581,39 @@ def test_amax_is_dropped_when_the_activation_is_edited_in_place(gpu_device):
         ref = torch.nn.functional.leaky_relu(conv + (lb.noise_const * lb.noise_strength).double() + lb.bias.double()[None, :, None, None], 0.2) * math.sqrt(2)
     err = float((out_edit.double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 4e-6, err
+
+
+@pytest.mark.parametrize('shape', [(4, 128, 64, 64, 64), (2, 64, 96, 32, 48), (1, 72, 64, 16, 128), (3, 40, 128, 33, 40)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('name', ['fp32', 'bf16x6', 'f16x3'])
+def test_transposed_strip_plan_equals_full_grid(gpu_device, shape, name):
+    """Round 4: the all-class transposed convolution on the h x w position grid + `tconv_strip_kernel` for output row 2h / column 2w
+    (plain fp32 FMAs) against the same launch on the (h + 1) x (w + 1) grid (IDE3D_MODCONV_NO_STRIP): every output outside the strip is
+    bit-equal, the strip agrees to fp32 rounding and with the float64 reference; padded rows (`pad_rows`) and `y_amax` included."""
+    import os
+    from torch_utils import hip_plugin
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, cin, h, w_, generator=g).to(gpu_device); wt = (torch.randn(cout, cin, 3, 3, generator=g) / 20).to(gpu_device)
+    s = (torch.randn(n, cin, generator=g) + 1).to(gpu_device); d = (torch.rand(n, cout, generator=g) + 0.5).to(gpu_device)
+    xam = _finite_amax(x)
+
+    def run():
+        am = torch.zeros(n, 32 * 64, device=gpu_device)
+        y = _mc()(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, arith=ARITH[name], x_amax=xam, y_amax=am, pad_rows=True)
+        return y, am
+
+    try:
+        os.environ['IDE3D_MODCONV_NO_STRIP'] = '1'
+        y_full, am_full = run()
+    finally:
+        os.environ.pop('IDE3D_MODCONV_NO_STRIP', None)
+    y_strip, am_strip = run()
+    assert y_strip.shape == (n, cout, 2 * h + 1, 2 * w_ + 1)
+    assert torch.equal(y_strip[:, :, :-1, :-1], y_full[:, :, :-1, :-1]), 'outputs outside the strip must not depend on the plan'
+    ref = torch.nn.functional.conv_transpose2d((x.double() * s.double()[:, :, None, None]).cpu(), wt.double().cpu().transpose(0, 1), stride=2) * d.double().cpu()[:, :, None, None]
+    scale = float(ref.abs().max())
+    for part, sl in (('row 2h', (slice(None), slice(None), -1, slice(None))), ('column 2w', (slice(None), slice(None), slice(None), -1))):
+        e_ref = float((y_strip[sl].double().cpu() - ref[sl]).abs().max()) / scale
+        e_full = float((y_strip[sl] - y_full[sl]).abs().max()) / scale
+        assert e_ref < 4e-6 and e_full < (2e-5 if name == 'bf16x3' else 8e-6), f'{part}: vs float64 {e_ref:.2e}, vs the full-grid plan {e_full:.2e}'
+    assert torch.equal(am_strip.amax(dim=1), y_strip.abs().amax(dim=(1, 2, 3))), 'y_amax must cover the strip'
