@@ -1107,6 +1107,175 @@ head_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int cchu
 }
 
 
+// Resident-weights form of the heads (round 4).  head_split_kernel lives for ONE 256- / 512-pixel tile: with one workgroup per CU (exclusive
+// residency) the launch is `tiles / 256` rounds of load -> multiply -> store in lockstep over the whole chip, the phases of a round do not
+// overlap (128 -> 192 @256: 4 rounds of ~28 us where the HBM bytes of a round take 10 and its MFMAs 8), and the barrier per K chunk keeps
+// the waves of a workgroup in the same phase as well.  Here the packed weights of the image's WHOLE K (<= 128 channels: 144 KB at 192 rows,
+// 24 KB at 32) are copied to LDS once per workgroup, and then the waves are independent: each takes 32-pixel tiles of its image in a
+// grid-stride loop with no barrier, loads the tile's activations straight into registers (lane = pixel, 8 channels of its k half per
+// chunk), multiplies against the LDS fragments and stores the accumulators directly (lane = pixel: every store writes two 128-byte runs).
+// MT = 6 (MFMA-heavy): the two waves of a SIMD alternate between waiting for HBM and multiplying.  MT = 1 (HBM-bound): the loads of the
+// NEXT tile are issued before the current one is multiplied (second register buffer), so a wave always has a tile in flight.
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* ptr) {
+    const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+template <int PARTS, int MT, int NCH>
+__global__ void __launch_bounds__(512, 2)
+head_resident_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int wgs_per_image, int tiles32) {
+    using K = HeadCfg<PARTS, MT>;
+    asm volatile("" ::: "v255");                                  // two waves per SIMD, both of this workgroup (section 4.2)
+    constexpr int NWV = 8, NBUF = (MT == 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) u32x4 s_a[NCH * K::A_UNITS + K::ROWS / 4 + 4];
+    float* const s_bi = reinterpret_cast<float*>(s_a + NCH * K::A_UNITS);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x % p.n, slot = blockIdx.x / p.n;      // consecutive workgroups (= XCDs) take different images
+    const int hw = p.h * p.w_;
+    const u32x4* __restrict__ wsrc = wp + (int64_t)n0 * NCH * K::A_UNITS;
+    constexpr int PIECES = NCH * K::A_UNITS / 64;
+    for (int i = wid; i < PIECES; i += NWV)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(s_a + i * 64), 16, 0, 0);
+    if (tid < K::ROWS) s_bi[tid] = (p.bias && tid < p.cout) ? p.bias[tid] : 0.f;      // (16-byte aligned: A_UNITS units of 16 bytes precede it)
+
+    // addresses as (wave-uniform 64-bit base in SGPRs) + (one 32-bit lane offset): 64 - 128 loads and 16 MT stores per tile with their own
+    // 64-bit lane addresses would not fit the register file
+    const char* const xbase = reinterpret_cast<const char*>(p.x + (int64_t)n0 * p.cin * hw);
+    char* const ybase = reinterpret_cast<char*>(p.y + (int64_t)n0 * p.cout * hw);
+    const unsigned x_lane = (unsigned)((8 * half) * hw + l32) * 4u, y_lane = (unsigned)((4 * half) * hw + l32) * 4u;
+    const int64_t plane = (int64_t)hw * 4;
+    const int wave0 = slot * NWV + wid, nwaves = wgs_per_image * NWV;
+    const float e_gain = p.gain, e_clamp = (p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+    float amax = 0.f;
+
+    float xr[NBUF][NCH][8];
+    auto fetch = [&](int t, auto buf_tag) {
+        constexpr int B = decltype(buf_tag)::value;
+        // (readfirstlane: the base stays a scalar the loop recomputes per tile; left alone the compiler turns the 64 - 128 addresses into as
+        // many 64-bit induction variables in vector registers and spills)
+        const char* src = uniform_ptr(xbase + (int64_t)t * 128);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 2)        // timing experiments only (wrong results): no activation loads
+                xr[B][c][e] = (float)(t + c + e);
+#else
+                xr[B][c][e] = *reinterpret_cast<const float*>(src + (c * 16 + e) * plane + x_lane);
+#endif
+            }
+    };
+    // The accumulators start from the bias (rows m * 32 + 8 g + 4 half + 0..3 of register group g: one 16-byte LDS read), so the finish is
+    // gain, clamp, store: the waves of a SIMD share one VALU, and with 96 values per lane and tile every instruction there counts
+    // (no loads / no stores / one product still took 44 of 106 us at 128 -> 192 @256 with six VALU instructions per value).
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    const float* const bi = s_bi + 4 * half;
+    f32x16 acc[MT];
+    auto compute = [&](auto buf_tag) {
+        constexpr int B = decltype(buf_tag)::value;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4a b4 = *reinterpret_cast<const f32x4a*>(bi + m * 32 + 8 * g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[m][4 * g + k] = b4[k];
+            }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            u32x4 bfrag[PARTS];
+            {
+                unsigned pk[4][PARTS];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_pair<PARTS>(xr[B][c][2 * e], xr[B][c][2 * e + 1], pk[e]);
+#pragma unroll
+                for (int q = 0; q < PARTS; ++q) bfrag[q] = u32x4{pk[0][q], pk[1][q], pk[2][q], pk[3][q]};
+            }
+            const u32x4* sa = s_a + c * K::A_UNITS + half * K::ROWS + l32;
+            constexpr int MG = (MT % 2 == 0) ? 2 : 1;               // row tiles multiplied together: two independent accumulator chains
+#pragma unroll
+            for (int m0 = 0; m0 < MT; m0 += MG) {
+                u32x4 af[MG][PARTS];
+#pragma unroll
+                for (int g = 0; g < MG; ++g)
+#pragma unroll
+                    for (int q = 0; q < PARTS; ++q) af[g][q] = sa[q * 2 * K::ROWS + (m0 + g) * 32];
+#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 4)        // timing experiments only (wrong results): one product instead of PARTS (PARTS + 1) / 2
+                constexpr int NQA = 1;
+#else
+                constexpr int NQA = PARTS;
+#endif
+#pragma unroll
+                for (int qa = 0; qa < NQA; ++qa)
+#pragma unroll
+                    for (int qb = 0; qa + qb < NQA; ++qb)
+#pragma unroll
+                        for (int g = 0; g < MG; ++g)
+                            acc[m0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[g][qa]), __builtin_bit_cast(bf16x8, bfrag[qb]), acc[m0 + g], 0, 0, 0);
+            }
+        }
+    };
+    // finish and store: register r of row tile m = row m * 32 + 8 (r / 4) + 4 half + r % 4; lane = pixel
+    const bool all_rows = (p.cout == K::ROWS), unit_gain = (e_gain == 1.f), want_amax = (p.y_amax != nullptr);
+    auto finish = [&](int t) {
+        char* dst = uniform_ptr(ybase + (int64_t)t * 128);
+        auto rows = [&](auto all_tag, auto gain_tag) {
+            constexpr bool ALL = decltype(all_tag)::value, UNIT = decltype(gain_tag)::value;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row_u = m * 32 + 8 * (r >> 2) + (r & 3);               // + 4 half
+                    if (ALL || row_u + 4 * half < p.cout) {
+                        float v = acc[m][r];
+                        if (!UNIT) v *= e_gain;
+                        v = __builtin_amdgcn_fmed3f(v, -e_clamp, e_clamp);
+#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 1)        // ... no stores (one that never happens keeps the values alive)
+                        if (v == 1.2345e-30f) *reinterpret_cast<float*>(dst + row_u * plane + y_lane) = v;
+#else
+                        *reinterpret_cast<float*>(dst + row_u * plane + y_lane) = v;
+#endif
+                        if (want_amax) amax_acc(amax, v);
+                    }
+                }
+        };
+        if (all_rows) { if (unit_gain) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+        else          { if (unit_gain) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+    };
+    using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, NBUF - 1>;
+    if (wave0 < tiles32) fetch(wave0, B0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the weights (LDS-DMA: invisible to the compiler's own wait counting)
+    __syncthreads();
+    if constexpr (NBUF == 1) {
+        // the next tile's loads go out between the last product and the finish: the register buffer is free, and the loads run ahead of the
+        // 96 stores instead of queueing behind them.  (Measured without effect: starting the second wave of every SIMD 1 / 2 / 4 x 8128
+        // cycles late to break a chip-wide load / multiply / store lockstep: 105.5 / 104.7 / 113.8 us against 104.8.)
+        for (int t = wave0; t < tiles32; t += nwaves) {
+            compute(B0{});
+            if (t + nwaves < tiles32) fetch(t + nwaves, B0{});
+            finish(t);
+        }
+    } else {
+        for (int t = wave0; t < tiles32; t += 2 * nwaves) {
+            if (t + nwaves < tiles32) fetch(t + nwaves, B1{});
+            compute(B0{});
+            finish(t);
+            if (t + nwaves < tiles32) {
+                if (t + 2 * nwaves < tiles32) fetch(t + 2 * nwaves, B0{});
+                compute(B1{});
+                finish(t + nwaves);
+            }
+        }
+    }
+    // every wave stays until the last one has finished (exclusive residency), and the image's amax is raised once per workgroup
+    __syncthreads();
+    if (p.y_amax != nullptr) amax_raise_block(p.y_amax, n0, amax, reinterpret_cast<float*>(s_a));
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Last output row / column of the transposed 3x3 convolution (round 4)
 // ------------------------------------------------------------------------------------------------
@@ -1497,6 +1666,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0;
+    int want_split = 0;                                         // split-K chosen together with the form (0 = by block count below)
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -1549,7 +1719,13 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         //   transposed 512 -> 256 in@64 (360 workgroups of 8 x 16): stays on 4 x 16, 4 waves 292 / 215 (8 waves: 401 / 325)
         if (kSpExclusive && !getenv("IDE3D_MODCONV_SP_OLDPLAN")) {
             if (pl.mode == MODE_CONV3) {
-                if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n >= 2 * kNumCU) pl.tile = 3;
+                const int64_t b256 = (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n;
+                if (pl.big == 2 && b256 >= 2 * kNumCU) pl.tile = 3;
+                // a quarter .. one workgroup per CU on 16 x 16 pixels (512 -> 512 @32 at batch 4: 64): 8 waves and split-K up to ONE workgroup
+                // per CU with >= 8 chunks each, instead of 8 x 16 pixels / 4 waves / split 6 = 768 workgroups of 2 - 6 chunks: 119 -> 93 us
+                if (pl.big == 1 && b256 < 2 * kNumCU && b256 * 4 >= kNumCU && cdiv(p.cin, 16) * b256 >= 8 * kNumCU && !getenv("IDE3D_MODCONV_NO_W8SPLIT")) {
+                    pl.tile = 3; want_split = (int)(kNumCU / b256);
+                }
             } else {
                 const int64_t b8 = (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n, b16 = (int64_t)pl.mblocks * cdiv(p.h + 1, 16) * cdiv(p.w_ + 1, 16) * p.n;
                 if (pl.big == 1) pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
@@ -1614,6 +1790,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         if (split > 16) split = 16;
         if (split < 1) split = 1;
     }
+    if (want_split > 0) split = want_split < pl.cchunks ? want_split : pl.cchunks;
+    static const int force_split = getenv("IDE3D_MODCONV_SPLITK") ? atoi(getenv("IDE3D_MODCONV_SPLITK")) : 0;   // experiments
+    if (force_split > 0 && !pl.strip) split = force_split < pl.cchunks ? force_split : pl.cchunks;
     g.chunks_per_split = cdiv(pl.cchunks, split);
     g.split_k = cdiv(pl.cchunks, g.chunks_per_split);
     pl.partial_floats = (g.split_k > 1) ? (int64_t)g.split_k * p.n * p.cout * pl.oh * pl.ow : 0;
@@ -1747,12 +1926,20 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
         const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
         const int tiles = cdiv(p.h * p.w_, 32 * head_waves(mt));
+        // resident-weights form: whole K in LDS (K = 64 / 128 at <= 32 rows, K = 128 at 192 rows), >= 2 tiles of 32 pixels per wave
+        const int hw_h = p.h * p.w_, wgs_img = kNumCU / p.n, tiles32 = hw_h / 32;
+        static const bool no_resident = getenv("IDE3D_HEAD_NO_RESIDENT") != nullptr;
+        const bool resident = !no_resident && kSpExclusive && p.cin % 16 == 0 && hw_h % 32 == 0 && wgs_img >= 1 && p.y_pitch == 0 &&
+                              ((mt == 1 && (cchunks == 4 || cchunks == 8)) || (mt == 6 && cchunks == 8)) && tiles32 >= 2 * wgs_img * 8;
+#define IDE3D_HEAD_RES(P, M, C) hipLaunchKernelGGL((head_resident_kernel<P, M, C>), dim3(p.n * wgs_img), dim3(512), 0, st_head, p, wu, wgs_img, tiles32)
 #define IDE3D_HEAD(P, M) do { \
             hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
-            hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * head_waves(M)), 0, st_head, p, wu, cchunks, tiles); } while (0)
+            if (resident) { if (M == 6) IDE3D_HEAD_RES(P, 6, 8); else if (cchunks == 4) IDE3D_HEAD_RES(P, 1, 4); else IDE3D_HEAD_RES(P, 1, 8); } \
+            else hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * head_waves(M)), 0, st_head, p, wu, cchunks, tiles); } while (0)
         if (parts == 2) { if (mt == 1) IDE3D_HEAD(2, 1); else IDE3D_HEAD(2, 6); }
         else            { if (mt == 1) IDE3D_HEAD(3, 1); else IDE3D_HEAD(3, 6); }
 #undef IDE3D_HEAD
+#undef IDE3D_HEAD_RES
         IDE3D_CHECK_LAUNCH("modconv2d (split-bf16 heads)");
         return IDE3D_OK;
     }

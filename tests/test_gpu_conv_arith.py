@@ -230,6 +230,29 @@ def test_per_image_heads_vs_float64(gpu_device, shape):
         assert err < TOL[name], f'{name}: {err:.3e}'
 
 
+@pytest.mark.parametrize('shape', [(4, 128, 192, 256, 256), (4, 64, 22, 256, 256), (4, 128, 22, 256, 256), (3, 128, 161, 256, 192), (1, 64, 3, 512, 512), (5, 128, 19, 256, 256)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_resident_weight_heads_vs_float64(gpu_device, shape):
+    """Round 4: heads whose packed weights fit LDS whole (K = 64 / 128) and whose images give every wave >= 2 tiles of 32 pixels run on
+    head_resident_kernel (barrier-free grid-stride waves, direct accumulator stores): against a float64 einsum, with the clamp active, an
+    odd number of images (85 / 51 workgroups per image), one image, unused rows (cout 161 / 19 / 3) and the recorded amax."""
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(n, cin, h, w, generator=g).to(gpu_device)
+    wt = (torch.randn(n, cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(gpu_device)
+    bias = torch.randn(cout, generator=g).to(gpu_device)
+    ref = ((torch.einsum('noc,nchw->nohw', wt[:, :, :, 0, 0].double(), x.double()) + bias.double()[None, :, None, None]) * 0.75).clamp(-2.0, 2.0)
+    assert float((ref.abs() == 2.0).float().mean()) > 1e-5, 'the clamp must be active'
+    for name in ('bf16x6', 'bf16x3', 'f16x3'):
+        amax = torch.zeros(n, 32 * 64, device=gpu_device)
+        y = _mc()(x, wt, None, None, None, 0.0, bias, 1, 0.0, 0.75, 2.0, arith=ARITH[name], y_amax=amax)
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert err < TOL[name if name != 'f16x3' else 'bf16x6'], f'{name}: {err:.3e}'          # f16x3: the heads stay on bf16x6
+        assert torch.equal(amax.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
+        y2 = _mc()(x, wt, None, None, None, 0.0, bias, 1, 0.0, 0.75, 2.0, arith=ARITH[name])
+        assert torch.equal(y, y2)
+
+
 # ---- round 3: the producers' amax, the f16x3 scales, adversarial operands ------------------------------------------------------------
 
 @pytest.mark.parametrize('shape', [(2, 40, 72, 37, 45, 0), (4, 512, 512, 16, 16, 0), (3, 64, 64, 40, 52, 2), (2, 16, 24, 9, 7, 0), (5, 8, 40, 4, 4, 0)],
