@@ -779,8 +779,14 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
         f16_scale(mm * xm, xs, xus);
     }
     const bool stages_patch = (NWV == 4) || wid < 4;
+#ifdef IDE3D_SP_DBG
+    const int c_begin_dbg = split * g.chunks_per_split; bool patch_done_dbg = false;
+#endif
     auto fetch_patch = [&](int c) {
         if (!stages_patch) return;
+#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 6)            // ... the patch is staged once (2) / loaded once and committed every chunk (4)
+        if (c > c_begin_dbg) return;
+#endif
         const int ci0 = c * K::KC + wid * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -792,6 +798,13 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     };
     auto commit_patch = [&](int buf) {
         if (!stages_patch) return;
+#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 10)           // (8: loaded every chunk, committed once)
+        if (buf != 0 || patch_done_dbg) {
+            for (int r = 0; r < K::NXR; ++r) asm volatile("" :: "v"(xreg[r][0]), "v"(xreg[r][1]), "v"(xreg[r][2]), "v"(xreg[r][3]));      // (the loads stay alive)
+            return;
+        }
+        patch_done_dbg = true;
+#endif
         unsigned char* const dst = reinterpret_cast<unsigned char*>(s_x + buf * K::X_UNITS) + ((wid >> 1) * K::NSLOT) * 16 + (wid & 1) * 8;
         // f16x3: the image scale joins the styles HERE, where the (scalar) style loads are waited for anyway — multiplied in fetch_patch it
         // forces `s_waitcnt lgkmcnt(0)` right behind the loads, in the middle of the hand-counted operand-read pipeline (scalar loads and
@@ -824,6 +837,9 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     constexpr int W_EARLY = (NWV == 8) ? (W_COL * 5 + 8) / 9 : W_COL;
     auto fetch_weights = [&](int stage, int buf, bool late = false) {
         const u32x4* src = wsrc + (int64_t)stage * K::W_UNITS;
+#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 1)            // timing experiments only (wrong results): the weights are fetched once
+        if (stage > c_begin_dbg * 3 + 1) return;
+#endif
         if (NWV == 4 && late) return;
         if (NWV == 8 && (late != (wid < 4))) return;
         const int m0 = late ? W_EARLY : 0, m1 = late ? W_COL : W_EARLY;
@@ -901,28 +917,41 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             constexpr int AHEAD_CAP = 15 / GRP - 1, AHEAD_SAFE = (NBUF - 1) * PARTS - 1;
             constexpr int AHEAD = (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) < AHEAD_SAFE ? (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) : AHEAD_SAFE;
             static_assert(AHEAD >= 1 && (AHEAD + 1) * GRP <= 15, "lgkmcnt is a 4-bit counter");
+            // All-class transposed form: the patch offset of tap (ky, kx) is ((ky == 2) ? 0 : 1, (kx == 2) ? 0 : 1), i.e. the taps kx = 0 and
+            // kx = 1 of a kernel row multiply the SAME patch fragment: it is read once (slot 0; kx = 2 reads into slot 1), which takes a third
+            // of the patch reads out of the LDS-bound loop (IDE3D_TA_BREUSE=0: one read per tap, the round-2 form)
+#ifndef IDE3D_TA_BREUSE
+#define IDE3D_TA_BREUSE 1
+#endif
+            constexpr bool B_REUSE = (MODE == MODE_TCONV3A) && IDE3D_TA_BREUSE >= 1 && NBUF == 2;
             u32x4 av[NBUF][K::MTW][PARTS], bv[NBUF][K::NTW][PARTS];
             auto issue = [&](auto ss) {
                 constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, T = KY * 3 + KX;
+                constexpr int BS = B_REUSE ? (KX == 2 ? 1 : 0) : B;
                 static_for<K::MTW>([&](auto ii) {
                     constexpr int I = decltype(ii)::value;
                     av[B][I][Q] = lds_read128_async<(((KX * PARTS + Q) * 2) * K::BM + I * 32) * 16>(a_base);
                 });
+                if constexpr (!(B_REUSE && KX == 1))
                 static_for<K::NTW>([&](auto jj) {
                     constexpr int J = decltype(jj)::value;
-                    bv[B][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
+                    bv[BS][J][Q] = lds_read128_async<(Q * 2 * K::NSLOT + tap_patch_offset<MODE, K::HW>(T)) * 16>(b_base[J]);
                 });
             };
             static_for<AHEAD>([&](auto ss) { issue(ss); });
             static_for<NGRP>([&](auto ss) {
                 constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, QC = tap_class<MODE>(KY * 3 + KX);
+                constexpr int BS = B_REUSE ? (KX == 2 ? 1 : 0) : B;
                 if constexpr (S + AHEAD < NGRP) issue(std::integral_constant<int, S + AHEAD>{});
-                constexpr int BEHIND = (NGRP - 1 - S < AHEAD) ? NGRP - 1 - S : AHEAD;            // groups issued after group S
-                lds_wait128<BEHIND * GRP>(av[B][0][Q]);
+                // reads issued after group S's own: those of the next min(AHEAD, groups left) groups
+                constexpr int PENDING = [] { int n = 0; for (int s2 = S + 1; s2 <= S + AHEAD && s2 < NGRP; ++s2) n += K::MTW + ((B_REUSE && s2 / PARTS == 1) ? 0 : K::NTW); return n; }();
+                lds_wait128<PENDING>(av[B][0][Q]);
 #pragma unroll
                 for (int i = 0; i < K::MTW; ++i) lds_pin128(av[B][i][Q]);
+                if constexpr (!(B_REUSE && KX == 1)) {
 #pragma unroll
-                for (int j = 0; j < K::NTW; ++j) lds_pin128(bv[B][j][Q]);
+                for (int j = 0; j < K::NTW; ++j) lds_pin128(bv[BS][j][Q]);
+                }
 #pragma unroll
                 for (int qa = 0; qa <= Q; ++qa)
 #pragma unroll
@@ -932,7 +961,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
                             for (int i = 0; i < K::MTW; ++i)
 #pragma unroll
                                 for (int j = 0; j < K::NTW; ++j)
-                                    acc[QC][i][j] = sp_mfma<F16>(av[B][i][qa], bv[B][j][qb], acc[QC][i][j]);
+                                    acc[QC][i][j] = sp_mfma<F16>(av[B][i][qa], bv[BS][j][qb], acc[QC][i][j]);
                         }
                     }
             });
