@@ -596,11 +596,14 @@ struct SpCfg {
     static constexpr int PW = 16, NWV = NWV_, NT = 64 * NWV;
     static constexpr int BN = PH * PW;
     static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;
-    static constexpr int WM = 2, WN = NWV / 2;
-    static constexpr int MTW = (BIG == 1) ? 2 : 1, NTW = BN / 32 / WN;
+    // wave grid WM x WN over (rows, pixels).  64-row blocks on 32 x 16 pixels (round 4): 1 x 8, i.e. 64 x 64 outputs per wave like the
+    // 128-row forms — the 2 x 4 grid of the 16 x 16-pixel form gives 32 x 64 per wave: 3 operand reads per 2 MFMAs instead of 4 per 4
+    static constexpr int BM = (BIG == 1) ? 128 : 64;
+    static constexpr int WM = (BIG == 2 && PH == 32) ? 1 : 2, WN = NWV / WM;
+    static constexpr int MTW = BM / 32 / WM, NTW = BN / 32 / WN;
+    static_assert(MTW >= 1 && MTW * 32 * WM == BM, "row block must split into 32-row MFMA tiles per wave");
     static_assert(NTW >= 1 && NTW * 32 * WN == BN, "pixel tile must split into 32-pixel MFMA tiles per wave");
     static constexpr int NLOAD = 4;                                  // waves that stage (patch: waves 0-3; weights: the last four)
-    static constexpr int BM = 64 * MTW;
     static constexpr int KC = 16;
     static constexpr int HP = PH + 2, HW = PW + 2, NSLOT = HP * HW;
     static constexpr int NS = PARTS * (PARTS + 1) / 2;               // products per k step
@@ -608,6 +611,7 @@ struct SpCfg {
     static constexpr int X_UNITS = PARTS * 2 * NSLOT;                // per patch buffer
     static constexpr int NXR = (NSLOT + 63) / 64;                    // patch pixels per lane
     static constexpr int LDS_BYTES = 16 * (WBUF * W_UNITS + 2 * X_UNITS);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
 __host__ __device__ inline int64_t sp_packed_units(int mblocks, int cchunks, int bm, int parts) { return (int64_t)mblocks * cchunks * 9 * parts * 2 * bm; }
@@ -1750,6 +1754,8 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
             if (pl.mode == MODE_CONV3) {
                 const int64_t b256 = (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n;
                 if (pl.big == 2 && b256 >= 2 * kNumCU) pl.tile = 3;
+                // 64 rows: 32 x 16 pixels (64 x 64 outputs per wave, half the tiles) while >= 2 workgroups per CU remain
+                if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h, 32) * cdiv(p.w_, 16) * p.n >= 2 * kNumCU && !getenv("IDE3D_MODCONV_NO_PH32")) pl.tile = 12;
                 // a quarter .. one workgroup per CU on 16 x 16 pixels (512 -> 512 @32 at batch 4: 64): 8 waves and split-K up to ONE workgroup
                 // per CU with >= 8 chunks each, instead of 8 x 16 pixels / 4 waves / split 6 = 768 workgroups of 2 - 6 chunks: 119 -> 93 us
                 if (pl.big == 1 && b256 < 2 * kNumCU && b256 * 4 >= kNumCU && cdiv(p.cin, 16) * b256 >= 8 * kNumCU && !getenv("IDE3D_MODCONV_NO_W8SPLIT")) {
@@ -1765,6 +1771,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         if (pl.mode == MODE_CONV3) {
             if (sp_rows == 8) pl.tile = 0;
             if (sp_rows == 16) pl.tile = 3;
+            if (sp_rows == 32 && pl.big == 2) pl.tile = 12;
         } else {
             if (pl.big == 1 && pl.tile == 7) pl.tile = 6;            // 128-row blocks: at most 8 x 16 positions (16 accumulators)
             if (sp_rows == 4) pl.tile = 4;
@@ -1772,7 +1779,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
             if (sp_rows == 16 && pl.big == 2) pl.tile = 7;
         }
         static const int sp_maxlds = getenv("IDE3D_MODCONV_SP_MAXLDS") ? atoi(getenv("IDE3D_MODCONV_SP_MAXLDS")) : 0;
-        const int ph = (pl.tile == 4) ? 4 : (pl.tile == 0 || pl.tile == 6) ? 8 : 16;
+        const int ph = (pl.tile == 4) ? 4 : (pl.tile == 0 || pl.tile == 6) ? 8 : (pl.tile == 12) ? 32 : 16;
         const int lds = 2 * 16 * (3 * pl.parts * 2 * pl.bm + pl.parts * 2 * (ph + 2) * 18);
         if (sp_maxlds && lds > sp_maxlds) pl.parts = 0;
     }
@@ -1782,7 +1789,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
         if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
     }
-    static const int TIv[12] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[12] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8}, PWv[12] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16};
+    static const int TIv[13] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[13] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8, 32}, PWv[13] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16, 16};
     if (pl.mode == MODE_TCONV3A) {                              // reserved whether or not this call's epilogue allows the strip plan (workspace sizing does not know)
         pl.strip_off = pl.aux_floats;
         pl.strip_floats = (int64_t)p.cin * 6 * (cdiv(p.cout, STRIP_CO) * STRIP_CO);
@@ -1881,6 +1888,10 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
         if (w8 & (MODE == MODE_CONV3 ? 1 : 2)) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
         else if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
         else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+    }
+    else if (pl.tile == 12) {
+        if constexpr (MODE == MODE_CONV3 && BIG == 2)
+            hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 32, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
         // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6);
