@@ -1711,6 +1711,15 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     }
     const int mind = (pl.mode == MODE_CONV3S2) ? ((pl.oh < pl.ow) ? pl.oh : pl.ow) : ((p.h < p.w_) ? p.h : p.w_);
     pl.tile = (mind >= 12 || p.w_batch_stride) ? 0 : (mind >= 6 ? 1 : 2);     // per-image weights need one image per tile
+    // small maps (4^2 .. 8^2) of wide 3x3 layers in a split arithmetic: the 8 x 16-pixel split-bf16 tile (one image per tile, most of it
+    // outside the map) with split-K 16 instead of the fp32 loop's several-images tiles: 35.5 -> 23.1 us at 512 -> 512 @8, 33.4 -> 20.2 @4
+    // (the launch is weight streaming + latency: 256 workgroups of two 16-channel chunks each)
+    if (arith != 1 && pl.mode == MODE_CONV3 && pl.tile != 0 && !p.w_batch_stride && pl.big != 0 && p.cin >= 256 && mc_env().tile < 0 &&
+        !getenv("IDE3D_MODCONV_NO_SMALLMAP")) {
+        pl.tile = 0;
+        const int c16 = cdiv(p.cin, 16);
+        want_split = c16 / 2 < 1 ? 1 : (c16 / 2 > 16 ? 16 : c16 / 2);
+    }
     // 256-pixel tiles (8 accumulators per wave) for big-cout 3x3 layers with enough work to fill the chip twice over
     if (pl.tile == 0 && pl.big == 1 && pl.mode != MODE_CONV1 && pl.mode != MODE_CONV3S2 && !p.w_batch_stride) {
         const int64_t blocks256 = (int64_t)pl.mblocks * cdiv(gh[0], 16) * cdiv(gw[0], 16) * p.n * ((pl.mode == MODE_TCONV3) ? 4 : 1);

@@ -223,7 +223,7 @@ def cases(device):
     conv_case('modconv transposed 3x3 128->64 in@256', 128, 64, 256, mode=2)
     conv_case('modconv transposed 3x3 32->128 in@128 (b256.conv0)', 32, 128, 128, mode=2)
     # the low-resolution half of the backbone (4^2 .. 32^2 at batch 4: a few dozen workgroups + split-K each)
-    for res in (32, 16, 8):
+    for res in (32, 16, 8, 4):
         conv_case(f'modconv 3x3 512->512 @{res} (low-res backbone)', 512, 512, res)
     for res in (32, 16, 8, 4):
         conv_case(f'modconv transposed 3x3 512->512 in@{res} (low-res backbone)', 512, 512, res, mode=2)
