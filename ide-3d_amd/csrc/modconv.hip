@@ -1700,6 +1700,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0;
     int want_split = 0;                                         // split-K chosen together with the form (0 = by block count below)
+    static const int split_min = getenv("IDE3D_MODCONV_SPLIT_MIN") ? atoi(getenv("IDE3D_MODCONV_SPLIT_MIN")) : 512;      // fewer workgroups than this: split-K
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -1812,7 +1813,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         const int ph = PHv[pl.tile], pw = PWv[pl.tile];
         const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
         const int64_t groups = cdiv(p.n, TIv[pl.tile]);
-        auto splits = [&](int64_t tiles) { return (int64_t)pl.mblocks * tiles * groups < 512 && pl.cchunks >= 8; };
+        auto splits = [&](int64_t tiles) { return (int64_t)pl.mblocks * tiles * groups < split_min && pl.cchunks >= 8; };
         if (t_main < t_full && !splits(t_main) && !splits(t_full)) {
             pl.strip = 1;
             for (int c = 0; c < 4; ++c) { gh[c] = p.h; gw[c] = p.w_; }
@@ -1829,7 +1830,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     g.debug = mc_env().debug;
     const int64_t base_blocks = (int64_t)g.mblocks * g.tile_base[4] * g.img_groups;
     int split = 1;
-    if (base_blocks < 512 && pl.cchunks >= 8) {
+    if (base_blocks < split_min && pl.cchunks >= 8) {
         split = (int)cdiv64(768, base_blocks);
         if (split > pl.cchunks / 4) split = pl.cchunks / 4;
         if (split > 16) split = 16;

@@ -23,7 +23,7 @@ if g:
     rec.update(d[g[0]])
     rec['hbm_traffic_bytes_per_launch'] = rec.get('hbm_traffic_bytes')
     json.dump(rec, open(os.path.join(out, 'gather_tile_pmc.json'), 'w'), indent=1)
-json.dump({'note': NOTE, 'kernels': cut(lambda k: 'modconv' in k or 'head_split' in k)}, open(os.path.join(out, 'modconv_pmc.json'), 'w'), indent=1)
+json.dump({'note': NOTE, 'kernels': cut(lambda k: 'modconv' in k or 'head_split' in k or 'head_resident' in k)}, open(os.path.join(out, 'modconv_pmc.json'), 'w'), indent=1)
 json.dump({'note': NOTE, 'kernels': cut(lambda k: 'render_rays' in k or 'sample_voxel' in k or 'density_kernel' in k)}, open(os.path.join(out, 'render_pmc.json'), 'w'), indent=1)
 json.dump({'note': NOTE, 'kernels': cut(lambda k: 'upfirdn2d' in k)}, open(os.path.join(out, 'fir_pmc.json'), 'w'), indent=1)
 print('cut', len(d), 'kernels')

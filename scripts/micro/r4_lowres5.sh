@@ -1,0 +1,11 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+export TMPDIR=/tmp
+run() { local only="$1"; shift; echo "== [$only] $*"; env "$@" timeout 120 python scripts/kernel_rooflines.py --iters 20 --only "$only" 2>&1 | grep -E "bf16x6" | cut -c1-120; }
+run "transposed 3x3 512->512 in@32" A=1
+run "transposed 3x3 512->512 in@32" IDE3D_MODCONV_SP_ROWS=8 IDE3D_MODCONV_SPLIT_MIN=256
+run "transposed 3x3 512->512 in@16" A=1
+run "transposed 3x3 512->512 in@16" IDE3D_MODCONV_SPLIT_MIN=256
+run "transposed 3x3 512->512 in@16" IDE3D_MODCONV_SPLIT_MIN=128
+run "transposed 3x3 512->512 in@8" A=1
+run "transposed 3x3 512->512 in@8" IDE3D_MODCONV_SPLIT_MIN=128
