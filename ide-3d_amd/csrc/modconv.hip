@@ -1700,6 +1700,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
     pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0;
     int want_split = 0;                                         // split-K chosen together with the form (0 = by block count below)
+    bool one_round = false;                                     // transposed 8-wave form chosen for whole rounds on the strip plan's grid: no split-K
     static const int split_min = getenv("IDE3D_MODCONV_SPLIT_MIN") ? atoi(getenv("IDE3D_MODCONV_SPLIT_MIN")) : 512;      // fewer workgroups than this: split-K
     // class grids
     int gh[4], gw[4];
@@ -1773,8 +1774,19 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 }
             } else {
                 const int64_t b8 = (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n, b16 = (int64_t)pl.mblocks * cdiv(p.h + 1, 16) * cdiv(p.w_ + 1, 16) * p.n;
-                if (pl.big == 1) pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
+                // on the h x w grid of a strip plan (below) the 8-wave form may come out at whole rounds of ONE workgroup per CU where the (h + 1) x
+                // (w + 1) grid did not: 512 -> 256 in@64 = 256 workgroups of 8 x 16 positions x 128 rows, no split-K: 241 -> 211 us (f16x3 181 -> 149)
+                // against 512 four-wave workgroups of 4 x 16; 512 -> 512 in@32 (64 rows): 149 -> 141 against 256 two-team workgroups
+                const bool strip_ok = !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !getenv("IDE3D_MODCONV_NO_ONE_ROUND");
+                const int64_t b8s = (int64_t)pl.mblocks * cdiv(p.h, 8) * cdiv(p.w_, 16) * p.n, b4s = (int64_t)pl.mblocks * cdiv(p.h, 4) * cdiv(p.w_, 16) * p.n;
+                auto rounds = [](int64_t blocks) { return (blocks + kNumCU - 1) / kNumCU; };
+                if (pl.big == 1) {
+                    pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
+                    // (a 4-wave workgroup of 4 x 16 positions is half the work at ~1.15 x the time per unit)
+                    if (pl.tile == 4 && strip_ok && b8s >= kNumCU && rounds(b8s) * 200 <= rounds(b4s) * 115) { pl.tile = 6; one_round = true; }
+                }
                 else if (b16 >= 2 * kNumCU) pl.tile = 7;
+                else if (strip_ok && (pl.mblocks & 1) == 0 && b8s >= kNumCU && rounds(b8s) * 100 <= rounds(b4s / 2) * 105) { pl.tile = 6; one_round = true; }
                 else if (p.h <= 16 && p.w_ <= 16 && (pl.mblocks & 1)) pl.tile = 6;       // 4^2 .. 16^2 maps with an odd block count (no team pairs): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves alone on a CU: 115 / 47 / 31; two 4-wave teams: 92 / 45 / 24)
             }
         }
@@ -1814,7 +1826,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
         const int64_t groups = cdiv(p.n, TIv[pl.tile]);
         auto splits = [&](int64_t tiles) { return (int64_t)pl.mblocks * tiles * groups < split_min && pl.cchunks >= 8; };
-        if (t_main < t_full && !splits(t_main) && !splits(t_full)) {
+        if (t_main < t_full && (one_round || (!splits(t_main) && !splits(t_full)))) {
             pl.strip = 1;
             for (int c = 0; c < 4; ++c) { gh[c] = p.h; gw[c] = p.w_; }
         }
@@ -1836,6 +1848,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         if (split > 16) split = 16;
         if (split < 1) split = 1;
     }
+    if (one_round) want_split = 1;
     if (want_split > 0) split = want_split < pl.cchunks ? want_split : pl.cchunks;
     static const int force_split = getenv("IDE3D_MODCONV_SPLITK") ? atoi(getenv("IDE3D_MODCONV_SPLITK")) : 0;   // experiments
     if (force_split > 0 && !pl.strip) split = force_split < pl.cchunks ? force_split : pl.cchunks;
