@@ -1748,8 +1748,12 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     }
     if (pl.mode == MODE_CONV1 && p.h == 1 && p.w_ % 4 == 0 && p.w_ >= 128) pl.tile = 5;   // flattened by flatten_pointwise()
     // split-bf16 loop: shared-weight 3x3 / all-class transposed layers on 16-pixel-wide tiles, 64- or 128-row blocks
-    // (layers with fewer than 3 K chunks stay on the fp32 loop: prologue + epilogue dominate, 32 -> 128 in@128 measured 81 vs 76 us)
-    if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 && p.cin > 32 &&
+    // (3x3 layers with fewer than 3 K chunks stay on the fp32 loop: prologue + epilogue dominate)
+    // (transposed layers from 32 input channels = 2 K chunks on: 32 -> 128 in@128 78.6 -> 60.5 us on the 8-wave strip-plan form; round 3's 81 vs 76
+    // the other way round was the 4-wave (h + 1) x (w + 1) form)
+    static const int sp_min_cin = getenv("IDE3D_MODCONV_SP_MINCIN") ? atoi(getenv("IDE3D_MODCONV_SP_MINCIN")) : 0;
+    const int min_cin = sp_min_cin ? sp_min_cin : (pl.mode == MODE_TCONV3A ? 32 : 33);
+    if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 && p.cin >= min_cin &&
         (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8 &&
         (!getenv("IDE3D_MODCONV_SP_MODES") || (atoi(getenv("IDE3D_MODCONV_SP_MODES")) & (pl.mode == MODE_CONV3 ? 1 : 2)))) {
         pl.parts = (arith == 3 || arith == 16) ? 2 : 3;

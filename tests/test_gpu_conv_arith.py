@@ -26,6 +26,7 @@ SHAPES = [  # n, cin, cout, h, w, mode
     (2, 40, 72, 37, 45, 0), (3, 64, 200, 33, 20, 0), (2, 512, 64, 16, 16, 0), (4, 128, 128, 256, 256, 0), (1, 17, 130, 12, 300, 0),
     (2, 40, 72, 37, 45, 2), (2, 96, 130, 20, 33, 2), (4, 512, 512, 16, 16, 2), (4, 128, 64, 256, 256, 2), (1, 33, 64, 13, 12, 2),
     (4, 48, 64, 250, 300, 0),      # 64 rows on 32 x 16-pixel tiles (round 4: >= 512 such tiles), ragged on both edges, 3 K chunks
+    (3, 32, 128, 40, 70, 2),       # 2 K chunks on the split loop (transposed layers from 32 input channels on, round 4)
     (4, 512, 512, 4, 4, 0), (3, 256, 130, 7, 9, 0),      # small maps of wide layers: 8 x 16-pixel split tile, split-K 16 / 8 (round 4)
 ]
 
