@@ -1309,6 +1309,70 @@ head_resident_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int w
 }
 
 
+// The heads of the LOW-resolution blocks (4^2 .. 16^2: 512 -> 192 per image, 0.01 - 0.2 GFLOP): on the matrix loops each cost a weight-packing
+// launch, a split-K main launch of a few dozen workgroups and a reduction launch — 20-22 us of latency for microseconds of work, three times
+// per frame.  Here: one launch of plain fp32 FMAs (exact products).  A workgroup owns HS_RB output rows of PX pixels of one image; its 16
+// waves are PX / 64 pixel groups x 1024 / PX slices of the input channels; a lane loads its pixel of every channel of its slice (coalesced) and multiplies
+// it with the rows' weights, which are wave-uniform (scalar loads straight from the folded [n, cout, cin] weights: no packing); the slices
+// meet in LDS, and thread (row, pixel) adds them, applies bias / gain / clamp and stores.
+// PX = pixels per workgroup: 256 (4 channel slices), or 64 for maps of <= 64 pixels (16 slices: a lane's whole slice is one batch of loads).
+// These launches are latency chains: 64 pixels x 16 slices with a lane's 32 loads in ONE batch: 5.3 us at 4^2 / 8^2 (8 per batch, 256 pixels: 11-12);
+// 256 pixels x 4 slices, 8 loads per batch (33 registers: three workgroups per CU): 12.3 us at 16^2 (32 per batch: 13.2, and 35 instead of 27 at 32^2,
+// where the matrix loop's 27.5 us stay).
+constexpr int HS_RB = 4, HS_THREADS = 1024;
+template <int PX, int HS_UN>
+__global__ void __launch_bounds__(HS_THREADS)
+head_small_kernel(ide3d_modconv_params p, int hw) {
+    constexpr int KS = HS_THREADS / PX;
+    __shared__ float s_red[KS][HS_RB][PX];
+    __shared__ float s_am[HS_THREADS / 64];
+    const int px_l = threadIdx.x % PX;
+    const int ks = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PX));          // channel slice: uniform per wave (PX is a multiple of 64)
+    const int row0 = blockIdx.x * HS_RB, n = blockIdx.z;
+    const int px_c = min((int)blockIdx.y * PX + px_l, hw - 1);
+    const int cq = (p.cin + KS - 1) / KS, c0 = ks * cq, c1 = min(c0 + cq, p.cin);
+    const float* __restrict__ xl = p.x + (int64_t)n * p.cin * hw + px_c;
+    const float* __restrict__ wr[HS_RB];
+#pragma unroll
+    for (int r = 0; r < HS_RB; ++r) wr[r] = p.w + (int64_t)n * p.w_batch_stride + (int64_t)min(row0 + r, p.cout - 1) * p.cin;
+    float acc[HS_RB] = {0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + HS_UN <= c1; c += HS_UN) {
+        float xv[HS_UN];
+#pragma unroll
+        for (int e = 0; e < HS_UN; ++e) xv[e] = xl[(int64_t)(c + e) * hw];
+#pragma unroll
+        for (int r = 0; r < HS_RB; ++r)
+#pragma unroll
+            for (int e = 0; e < HS_UN; ++e) acc[r] = fmaf(xv[e], wr[r][c + e], acc[r]);
+    }
+    for (; c < c1; ++c) {
+        const float xv = xl[(int64_t)c * hw];
+#pragma unroll
+        for (int r = 0; r < HS_RB; ++r) acc[r] = fmaf(xv, wr[r][c], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < HS_RB; ++r) s_red[ks][r][px_l] = acc[r];
+    __syncthreads();
+    // thread (row, pixel) of the first HS_RB x PX: slices added in slice order (deterministic)
+    float amax = 0.f;
+    if (threadIdx.x < HS_RB * PX) {
+        const int r = threadIdx.x / PX, row = row0 + r, px = (int)blockIdx.y * PX + px_l;
+        float v = s_red[0][r][px_l];
+#pragma unroll
+        for (int q = 1; q < KS; ++q) v += s_red[q][r][px_l];
+        if (row < p.cout && px < hw) {
+            if (p.bias) v += p.bias[row];
+            v *= p.gain;
+            if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            p.y[((int64_t)n * p.cout + row) * hw + px] = v;
+            amax_acc(amax, v);
+        }
+    }
+    if (p.y_amax != nullptr) amax_raise_block(p.y_amax, n, amax, s_am);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Last output row / column of the transposed 3x3 convolution (round 4)
 // ------------------------------------------------------------------------------------------------
@@ -1987,6 +2051,16 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
     IDE3D_CHECK_ARG(p.y_pitch == 0 || (p.mode == 2 && p.y_pitch >= 2 * p.w_ + 1), "modconv2d: y_pitch is the row pitch of a transposed convolution's output (>= 2 w + 1), or 0");
     hipStream_t st_head = (hipStream_t)stream;
+    {   // per-image linear 1x1 convolution on a small map: one launch of fp32 FMAs (head_small_kernel) in every arithmetic
+        static const bool no_small = getenv("IDE3D_HEAD_NO_SMALL") != nullptr;
+        const int64_t hw = (int64_t)p.h * p.w_;
+        if (!no_small && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 && hw <= 256 && p.y_pitch == 0 && p.n <= 65535) {
+            if (hw <= 64) hipLaunchKernelGGL((head_small_kernel<64, 32>), dim3(cdiv(p.cout, HS_RB), 1, p.n), dim3(HS_THREADS), 0, st_head, p, (int)hw);
+            else          hipLaunchKernelGGL((head_small_kernel<256, 8>), dim3(cdiv(p.cout, HS_RB), cdiv((int)hw, 256), p.n), dim3(HS_THREADS), 0, st_head, p, (int)hw);
+            IDE3D_CHECK_LAUNCH("modconv2d (small-map heads)");
+            return IDE3D_OK;
+        }
+    }
     if (head_split_applies(p, resolve_arith(p.arith))) {
         const int parts = resolve_arith(p.arith) == 3 ? 2 : 3, mt = p.cout <= 32 ? 1 : 6, cchunks = cdiv(p.cin, 16);     // f16x3: the heads stay on bf16x6
         IDE3D_CHECK_ARG(p.workspace_bytes >= head_packed_units(p.n, cchunks, parts, mt) * 16, "modconv2d: workspace too small for the packed head weights");

@@ -216,7 +216,8 @@ def test_graphed_renderer_is_deterministic_with_split_arithmetic(gpu_device, ari
         hip_plugin.conv_arithmetic('default')
 
 
-@pytest.mark.parametrize('shape', [(2, 64, 22, 200, 180), (4, 128, 192, 128, 130), (1, 100, 19, 255, 257), (2, 256, 192, 32, 32)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('shape', [(2, 64, 22, 200, 180), (4, 128, 192, 128, 130), (1, 100, 19, 255, 257), (2, 256, 192, 32, 32), (2, 512, 192, 64, 64),
+                                   (4, 512, 192, 8, 8), (3, 101, 19, 5, 7), (4, 512, 192, 16, 16), (2, 7, 5, 20, 20), (2, 512, 190, 30, 33)], ids=lambda s: 'x'.join(map(str, s)))
 def test_per_image_heads_vs_float64(gpu_device, shape):
     """The dual toRGB + toSeg heads (per-image folded 1x1 weights, bias, clamp) on the split-bf16 head kernel (>= 512 workgroups of 128 pixels, <= 32 or
     161..192 outputs; the last shape stays on the fp32 loop) against a float64 einsum; ragged pixel counts and a channel count that is no multiple of 16."""
