@@ -1703,6 +1703,17 @@ static const McEnv& mc_env() {
     return e;
 }
 
+// Experiment switches of plan_conv (A/B runs of scripts/micro/: each is the "before" of a plan rule and is documented where the rule is),
+// read once.  IDE3D_MODCONV_NO_STRIP alone is read per call: tests/test_gpu_conv_arith.py flips it inside one process.
+struct PlanKnobs { bool ta_bm64, head_bm128, ta_kc8, no_smallmap, ta_old, sp_oldplan, no_ph32, no_w8split, no_one_round; int sp_modes; };
+static const PlanKnobs& plan_knobs() {
+    auto on = [](const char* name) { return getenv(name) != nullptr; };
+    static const PlanKnobs k = {on("IDE3D_MODCONV_TA_BM64"), on("IDE3D_MODCONV_HEAD_BM128"), on("IDE3D_MODCONV_TA_KC8"), on("IDE3D_MODCONV_NO_SMALLMAP"),
+                                on("IDE3D_MODCONV_TA_OLD"), on("IDE3D_MODCONV_SP_OLDPLAN"), on("IDE3D_MODCONV_NO_PH32"), on("IDE3D_MODCONV_NO_W8SPLIT"),
+                                on("IDE3D_MODCONV_NO_ONE_ROUND"), getenv("IDE3D_MODCONV_SP_MODES") ? atoi(getenv("IDE3D_MODCONV_SP_MODES")) : 3};
+    return k;
+}
+
 // A 1x1 convolution does not see the image shape: h x w is treated as one row, tiled in runs of 128 pixels whose patch
 // rows are contiguous in memory (16-byte staging, 128-byte output runs).  Needs 16-byte aligned rows.
 static ide3d_modconv_params flatten_pointwise(const ide3d_modconv_params& in) {
@@ -1747,14 +1758,14 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         // the block count (512 -> 512 in@32: 432 -> 864 blocks, measured +5 %)
         const int64_t blocks128 = (int64_t)cdiv(p.cout, 128) * cdiv(p.h + 1, 4) * cdiv(p.w_ + 1, 16) * p.n;
         static const bool old_plan = getenv("IDE3D_MODCONV_TA_OLD") != nullptr;
-        if ((blocks128 < 3 * kNumCU * 3 / 4 && !old_plan) || mc_env().ta_rows == 64 || getenv("IDE3D_MODCONV_TA_BM64")) pl.bm = 64;
+        if ((blocks128 < 3 * kNumCU * 3 / 4 && !old_plan) || mc_env().ta_rows == 64 || plan_knobs().ta_bm64) pl.bm = 64;
     }
     // 1x1 heads with cout = 192 (96 + 96 tri-plane channels): three 64-row blocks instead of 128 + 64 rows padded to 128
-    if (p.k == 1 && pl.bm == 128 && p.cout % 128 != 0 && p.cout % 64 == 0 && !getenv("IDE3D_MODCONV_HEAD_BM128")) pl.bm = 64;
+    if (p.k == 1 && pl.bm == 128 && p.cout % 128 != 0 && p.cout % 64 == 0 && !plan_knobs().head_bm128) pl.bm = 64;
     // experiment (IDE3D_MODCONV_TA_KC8): all-class transposed conv as 64-row blocks x 8 x 16 positions x 8 input channels per chunk:
     // 72 MFMAs per wave and barrier instead of 36, 18 KB of weights streamed per 72 MFMAs instead of per 36
     bool ta_kc8 = false;
-    if (allcls && p.cin % 8 == 0 && getenv("IDE3D_MODCONV_TA_KC8")) { pl.bm = 64; ta_kc8 = true; }
+    if (allcls && p.cin % 8 == 0 && plan_knobs().ta_kc8) { pl.bm = 64; ta_kc8 = true; }
     pl.big = pl.bm == 128 ? 1 : (pl.bm == 64 ? 2 : 0);
     pl.kc = ta_kc8 ? 8 : mc_kc(p.k); pl.taps = p.k * p.k;
     pl.mblocks = cdiv(p.cout, pl.bm); pl.cchunks = cdiv(p.cin, pl.kc);
@@ -1781,7 +1792,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     // outside the map) with split-K 16 instead of the fp32 loop's several-images tiles: 35.5 -> 23.1 us at 512 -> 512 @8, 33.4 -> 20.2 @4
     // (the launch is weight streaming + latency: 256 workgroups of two 16-channel chunks each)
     if (arith != 1 && pl.mode == MODE_CONV3 && pl.tile != 0 && !p.w_batch_stride && pl.big != 0 && p.cin >= 256 && mc_env().tile < 0 &&
-        !getenv("IDE3D_MODCONV_NO_SMALLMAP")) {
+        !plan_knobs().no_smallmap) {
         pl.tile = 0;
         const int c16 = cdiv(p.cin, 16);
         want_split = c16 / 2 < 1 ? 1 : (c16 / 2 > 16 ? 16 : c16 / 2);
@@ -1800,7 +1811,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         pl.tile = 4;
         // 64-row blocks have registers for 8 x 16 positions (8 accumulators per wave): half the weight bytes streamed per MFMA
         // (128 -> 64 in@256: measured +3.5 %) as long as enough blocks remain
-        if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n >= 4 * kNumCU && !getenv("IDE3D_MODCONV_TA_OLD")) pl.tile = 6;
+        if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h + 1, 8) * cdiv(p.w_ + 1, 16) * p.n >= 4 * kNumCU && !plan_knobs().ta_old) pl.tile = 6;
         const int rows = mc_env().ta_rows ? mc_env().ta_rows : 0;
         if (rows == 4) pl.tile = 4;
         if (ta_kc8) pl.tile = 11;
@@ -1819,7 +1830,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     const int min_cin = sp_min_cin ? sp_min_cin : (pl.mode == MODE_TCONV3A ? 32 : 33);
     if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 && p.cin >= min_cin &&
         (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8 &&
-        (!getenv("IDE3D_MODCONV_SP_MODES") || (atoi(getenv("IDE3D_MODCONV_SP_MODES")) & (pl.mode == MODE_CONV3 ? 1 : 2)))) {
+        (plan_knobs().sp_modes & (pl.mode == MODE_CONV3 ? 1 : 2))) {
         pl.parts = (arith == 3 || arith == 16) ? 2 : 3;
         pl.f16 = (arith == 16) ? 1 : 0;
         static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
@@ -1829,15 +1840,15 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         //   transposed 256 -> 128 in@128: 8 x 16 positions x 128 rows, 8 waves 250 / 175 (4 x 16, 4 waves: 269 / 207)
         //   transposed 128 -> 64 in@256: 16 x 16 positions x 64 rows, 8 waves 270 / 211 (8 x 16, 4 waves: 318 / 263)
         //   transposed 512 -> 256 in@64 (360 workgroups of 8 x 16): stays on 4 x 16, 4 waves 292 / 215 (8 waves: 401 / 325)
-        if (kSpExclusive && !getenv("IDE3D_MODCONV_SP_OLDPLAN")) {
+        if (kSpExclusive && !plan_knobs().sp_oldplan) {
             if (pl.mode == MODE_CONV3) {
                 const int64_t b256 = (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n;
                 if (pl.big == 2 && b256 >= 2 * kNumCU) pl.tile = 3;
                 // 64 rows: 32 x 16 pixels (64 x 64 outputs per wave, half the tiles) while >= 2 workgroups per CU remain
-                if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h, 32) * cdiv(p.w_, 16) * p.n >= 2 * kNumCU && !getenv("IDE3D_MODCONV_NO_PH32")) pl.tile = 12;
+                if (pl.big == 2 && (int64_t)pl.mblocks * cdiv(p.h, 32) * cdiv(p.w_, 16) * p.n >= 2 * kNumCU && !plan_knobs().no_ph32) pl.tile = 12;
                 // a quarter .. one workgroup per CU on 16 x 16 pixels (512 -> 512 @32 at batch 4: 64): 8 waves and split-K up to ONE workgroup
                 // per CU with >= 8 chunks each, instead of 8 x 16 pixels / 4 waves / split 6 = 768 workgroups of 2 - 6 chunks: 119 -> 93 us
-                if (pl.big == 1 && b256 < 2 * kNumCU && b256 * 4 >= kNumCU && cdiv(p.cin, 16) * b256 >= 8 * kNumCU && !getenv("IDE3D_MODCONV_NO_W8SPLIT")) {
+                if (pl.big == 1 && b256 < 2 * kNumCU && b256 * 4 >= kNumCU && cdiv(p.cin, 16) * b256 >= 8 * kNumCU && !plan_knobs().no_w8split) {
                     pl.tile = 3; want_split = (int)(kNumCU / b256);
                 }
             } else {
@@ -1845,7 +1856,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 // on the h x w grid of a strip plan (below) the 8-wave form may come out at whole rounds of ONE workgroup per CU where the (h + 1) x
                 // (w + 1) grid did not: 512 -> 256 in@64 = 256 workgroups of 8 x 16 positions x 128 rows, no split-K: 241 -> 211 us (f16x3 181 -> 149)
                 // against 512 four-wave workgroups of 4 x 16; 512 -> 512 in@32 (64 rows): 149 -> 141 against 256 two-team workgroups
-                const bool strip_ok = !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !getenv("IDE3D_MODCONV_NO_ONE_ROUND");
+                const bool strip_ok = !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
                 const int64_t b8s = (int64_t)pl.mblocks * cdiv(p.h, 8) * cdiv(p.w_, 16) * p.n, b4s = (int64_t)pl.mblocks * cdiv(p.h, 4) * cdiv(p.w_, 16) * p.n;
                 auto rounds = [](int64_t blocks) { return (blocks + kNumCU - 1) / kNumCU; };
                 if (pl.big == 1) {
