@@ -49,12 +49,18 @@ struct MapArgs {
 // occupancy query, `mapping_resident`), and should that ever fail — a CU mask, a foreign kernel pinning the LDS — the kernel traps after
 // ~2^22 polls (seconds) with the error word set: a reported launch failure, also inside a hipGraph replay, instead of a hung GPU.
 constexpr unsigned MAP_SPIN_LIMIT = 1u << 22;
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+// `between` (all threads) runs after this workgroup has arrived and before it starts polling: work that does not depend on the other workgroups
+// (round 4: the loads of the next layer's weights) and must not delay the arrival.
+template <class F>
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, F&& between) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    between();
+    if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
@@ -114,6 +120,56 @@ __device__ __forceinline__ void gemv_rows(const float* __restrict__ s_x, int n, 
     }
 }
 
+// The common shape (every wave owns ONE block of RB rows per layer and all images fit one register block: 512-wide layers on 64 workgroups,
+// n <= MAP_NB): the weight block of a layer as a separate step, so that the kernel can request layer l + 1's weights BEFORE it enters the
+// grid barrier of layer l (they do not depend on the activations): the ~2-3 us of HBM / MALL latency per layer overlap the barrier.
+constexpr int MAP_NS = MAP_MAX_K / (kWave * 4);
+template <int RB>
+__device__ __forceinline__ void gemv_load_block(float4 (&a)[MAP_NS][RB], int K, const float* __restrict__ W, int i0, int r1) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int t = 0; t < MAP_NS; ++t) {
+        const int k = lane * 4 + t * kWave * 4;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            a[t][r] = (k < K) ? *reinterpret_cast<const float4*>(W + (int64_t)min(i0 + r, r1 - 1) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int RB>
+__device__ __forceinline__ void gemv_block(const float4 (&a)[MAP_NS][RB], const float* __restrict__ s_x, int n, int K, const float* __restrict__ b,
+                                           int i0, int r1, float wg, float bg, float alpha, float gain, float* __restrict__ out, int out_pitch) {
+    const int lane = lane_id();
+    float acc[RB][MAP_NB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int m = 0; m < MAP_NB; ++m) acc[r][m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAP_NS; ++t) {
+        const int k = min(lane * 4 + t * kWave * 4, K - 4);          // a[t] is zero beyond K
+#pragma unroll
+        for (int m = 0; m < MAP_NB; ++m) {
+            const float4 xk = *reinterpret_cast<const float4*>(s_x + min(m, n - 1) * MAP_MAX_K + k);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r][m] += (a[t][r].x * xk.x + a[t][r].y * xk.y) + (a[t][r].z * xk.z + a[t][r].w * xk.w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int m = 0; m < MAP_NB; ++m) {
+            float v = acc[r][m];
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int i = i0 + r;
+            if (lane == 0 && i < r1 && m < n) {
+                v = v * wg + (b ? b[i] * bg : 0.f);
+                v = (v > 0.f ? v : v * alpha) * gain;
+                out[m * out_pitch + i] = v;
+            }
+        }
+}
+
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -132,6 +188,18 @@ mapping_kernel(const MapArgs p) {
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     // ---- input stage (redundantly in every workgroup: 512 + 512 x 25 multiply-adds per image) ----
     const int K0 = p.z_dim + p.embed;
+    constexpr int RB = 2;
+    const int wid = tid >> 6, nw = (int)(blockDim.x >> 6);
+    // one block of RB rows per wave and layer, all images in one register block: the weights of a layer are requested one step early — layer 0's
+    // here, in front of the input stage; layer l + 1's inside the grid barrier of layer l
+    auto one_block = [&](int l) { return l < p.layers && cdiv(p.fc_out[l], nwg) <= nw * RB && p.n <= MAP_NB; };
+    float4 a_pre[MAP_NS][RB];
+    bool have_pre = false;
+    if (one_block(0)) {
+        const int O0 = p.fc_out[0], per0 = cdiv(O0, nwg), q0 = wg * per0, q1 = min(O0, q0 + per0), j0 = q0 + wid * RB;
+        if (j0 < q1) gemv_load_block<RB>(a_pre, K0, p.fc_w[0], j0, q1);
+        have_pre = true;
+    }
     for (int m = 0; m < p.n; ++m) {
         float sq = 0.f;
         for (int k = tid; k < p.z_dim; k += blockDim.x) { const float v = p.z[m * p.z_dim + k]; sq += v * v; }
@@ -154,9 +222,20 @@ mapping_kernel(const MapArgs p) {
         const int O = p.fc_out[l];
         const int per = cdiv(O, nwg), r0 = wg * per, r1 = min(O, r0 + per);
         float* out = p.act + (size_t)l * MAP_MAX_N * MAP_MAX_K;
-        if (r0 < r1)
+        if (one_block(l)) {
+            const int i0 = r0 + wid * RB;
+            if (!have_pre && i0 < r1) gemv_load_block<RB>(a_pre, K, p.fc_w[l], i0, r1);
+            if (i0 < r1) gemv_block<RB>(a_pre, s_x, p.n, K, p.fc_b[l], i0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
+        } else if (r0 < r1)
             gemv_rows<2>(s_x, p.n, K, p.fc_w[l], p.fc_b[l], r0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
-        grid_barrier(p.counter, (unsigned)(l + 1) * nwg);
+        have_pre = false;
+        grid_barrier(p.counter, (unsigned)(l + 1) * nwg, [&] {
+            if (one_block(l + 1)) {
+                const int O2 = p.fc_out[l + 1], per2 = cdiv(O2, nwg), q0 = wg * per2, q1 = min(O2, q0 + per2), j0 = q0 + wid * RB;
+                if (j0 < q1) gemv_load_block<RB>(a_pre, O, p.fc_w[l + 1], j0, q1);
+                have_pre = true;
+            }
+        });
         for (int i = tid * 4; i < p.n * O; i += blockDim.x * 4) {          // O % 4 == 0: 16-byte loads
             const int m = i / O, k = i - m * O;
             *reinterpret_cast<float4*>(s_x + m * MAP_MAX_K + k) = *reinterpret_cast<const float4*>(out + m * MAP_MAX_K + k);
