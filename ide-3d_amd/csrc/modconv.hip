@@ -1745,6 +1745,9 @@ static int conv_arith_default() {
 }
 static int resolve_arith(int a) { return (a == 1 || a == 3 || a == 6 || a == 16) ? a : conv_arith_default(); }
 
+// tile index (ConvPlan::tile) -> images per tile, tile height, tile width (pixels; transposed all-class form: grid positions)
+static const int TIv[13] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[13] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8, 32}, PWv[13] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16, 16};
+
 static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     // all-class form from 4 x 4 maps on (round 3: the per-class form took 65 / 78 us for the 0.3-GFLOP layers at 4^2 / 8^2; 962 -> 974-981
@@ -1890,7 +1893,6 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         pl.packed_floats = sp_packed_units(pl.mblocks, pl.cchunks, pl.bm, pl.parts) * 4;
         if (pl.f16) pl.aux_floats = 2 * (int64_t)pl.mblocks * pl.bm;
     }
-    static const int TIv[13] = {1, 2, 8, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, PHv[13] = {8, 8, 4, 16, 4, 1, 8, 16, 8, 16, 1, 8, 32}, PWv[13] = {16, 8, 4, 16, 16, 128, 16, 16, 16, 16, 256, 16, 16};
     if (pl.mode == MODE_TCONV3A) {                              // reserved whether or not this call's epilogue allows the strip plan (workspace sizing does not know)
         pl.strip_off = pl.aux_floats;
         pl.strip_floats = (int64_t)p.cin * 6 * (cdiv(p.cout, STRIP_CO) * STRIP_CO);
@@ -1963,20 +1965,34 @@ static void launch_tiles(const ide3d_modconv_params& p, const ConvPlan& pl, cons
 
 
 constexpr int kSpW8Default = kSpExclusive ? 2 : 0;
+// Waves per workgroup (per team) of the split-bf16 launch of a plan, and whether two 4-wave teams share a workgroup: the ONE place that decides
+// it (launch_split launches what this says; ide3d_modconv_plan reports it).
+// 8-wave forms (two of this workgroup's waves per SIMD: exclusive residency without giving up the second wave): IDE3D_SP_W8 bit 0 =
+// 3x3 on 8 x 16 pixels, bit 1 = all-class transposed 3x3 (8 x 16 positions at 128 rows, 16 x 16 at 64 rows); IDE3D_MODCONV_SP_W4 = 4 waves
+// on the 16 x 16 tiles as well; IDE3D_SP_NO_TEAMS = no two-team workgroups.
+struct SpForm { int waves; bool teams; };
+static SpForm sp_form(const ConvPlan& pl) {
+    static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
+    static const bool no_teams = getenv("IDE3D_SP_NO_TEAMS") != nullptr, no8 = getenv("IDE3D_MODCONV_SP_W4") != nullptr;
+    const bool conv3 = (pl.mode == MODE_CONV3);
+    // 64-row blocks, even block count: two teams per workgroup (128-row blocks: LDS does not fit twice in bf16x6, and in f16x3 the teams measured 233 vs 217 us at 512 -> 256 in@64)
+    if (pl.tile == 4) return {4, !conv3 && pl.big == 2 && kSpExclusive && !no_teams && (pl.mblocks & 1) == 0};
+    if (pl.tile == 0 || pl.tile == 6) return {(w8 & (conv3 ? 1 : 2)) ? 8 : 4, false};
+    if (pl.tile == 12) return {8, false};
+    // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6)
+    return {(!no8 && (conv3 || (w8 & 2))) ? 8 : 4, false};
+}
 template <int MODE, int BIG, int PARTS, int F16 = 0>
 static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, const float* wp, float* partial, hipStream_t st) {
     const ConvGeom& g = pl.g;
     const unsigned nblocks = (unsigned)((int64_t)g.mblocks * g.tile_base[4] * g.img_groups * g.split_k);
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
     const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale] behind the packed weights
-    // 8-wave forms (two of this workgroup's waves per SIMD: exclusive residency without giving up the second wave): IDE3D_SP_W8 bit 0 =
-    // 3x3 on 8 x 16 pixels, bit 1 = all-class transposed 3x3 (8 x 16 positions at 128 rows, 16 x 16 at 64 rows)
-    static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
+    const SpForm form = sp_form(pl);
     if (pl.tile == 4) {
         if constexpr (MODE == MODE_TCONV3A) {
-            static const bool no_teams = getenv("IDE3D_SP_NO_TEAMS") != nullptr;
-            if constexpr (BIG == 2) {          // 64-row blocks, even block count: two teams per workgroup (128-row blocks: LDS does not fit twice in bf16x6, and in f16x3 the teams measured 233 vs 217 us at 512 -> 256 in@64)
-                if (kSpExclusive && !no_teams && (g.mblocks & 1) == 0) {
+            if constexpr (BIG == 2) {
+                if (form.teams) {
                     hipLaunchKernelGGL((modconv_split_teams_kernel<MODE, BIG, 4, PARTS, 2, F16>), dim3(nblocks / 2), dim3(512), 0, st, p, wu, partial, g, ru);
                     return;
                 }
@@ -1987,7 +2003,7 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr && !kSpExclusive;
-        if (w8 & (MODE == MODE_CONV3 ? 1 : 2)) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+        if (form.waves == 8) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
         else if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
         else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
@@ -1996,11 +2012,7 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
             hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 32, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
-        // 16 x 16 pixels: 8 waves with time-shifted roles (3x3: 333 vs 352 us at 128 -> 128 @256, 321 vs 335 at 256 -> 256 @128, bf16x6);
-        // IDE3D_MODCONV_SP_W4 = 4 waves everywhere
-        static const bool no8 = getenv("IDE3D_MODCONV_SP_W4") != nullptr;
-        const bool eight = !no8 && (MODE == MODE_CONV3 || (w8 & 2));
-        if (eight) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+        if (form.waves == 8) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
         else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
     }
 }
@@ -2014,6 +2026,21 @@ static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
            (p.cout <= 32 || (p.cout > 160 && p.cout <= 192)) && p.cin >= 32 &&
            (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 32 * ide3d::head_waves(p.cout <= 32 ? 1 : 6)) >= ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
                                                                               // (512 channels @32^2 / @64^2: 54 us against 16 / 40 us on the fp32 loop)
+}
+
+// per-image linear 1x1 convolution on a small map: one launch of fp32 FMAs (head_small_kernel) in every arithmetic
+static bool head_small_applies(const ide3d_modconv_params& p) {
+    static const bool no_small = getenv("IDE3D_HEAD_NO_SMALL") != nullptr;
+    return !no_small && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 && (int64_t)p.h * p.w_ <= 256 &&
+           p.y_pitch == 0 && p.n <= 65535;
+}
+// resident-weights form of the split heads: whole K in LDS (K = 64 / 128 at <= 32 rows, K = 128 at 192 rows), >= 2 tiles of 32 pixels per wave
+static bool head_resident_applies(const ide3d_modconv_params& p) {
+    static const bool no_resident = getenv("IDE3D_HEAD_NO_RESIDENT") != nullptr;
+    const int mt = p.cout <= 32 ? 1 : 6, cchunks = ide3d::cdiv(p.cin, 16);
+    const int hw = p.h * p.w_, wgs_img = ide3d::kNumCU / p.n, tiles32 = hw / 32;
+    return !no_resident && ide3d::kSpExclusive && p.cin % 16 == 0 && hw % 32 == 0 && wgs_img >= 1 && p.y_pitch == 0 &&
+           ((mt == 1 && (cchunks == 4 || cchunks == 8)) || (mt == 6 && cchunks == 8)) && tiles32 >= 2 * wgs_img * 8;
 }
 
 static int check_modconv(const ide3d_modconv_params& p) {
@@ -2062,10 +2089,9 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
     IDE3D_CHECK_ARG(p.act == 1 || p.act == 3, "modconv2d: act must be linear (1) or lrelu (3)");
     IDE3D_CHECK_ARG(p.y_pitch == 0 || (p.mode == 2 && p.y_pitch >= 2 * p.w_ + 1), "modconv2d: y_pitch is the row pitch of a transposed convolution's output (>= 2 w + 1), or 0");
     hipStream_t st_head = (hipStream_t)stream;
-    {   // per-image linear 1x1 convolution on a small map: one launch of fp32 FMAs (head_small_kernel) in every arithmetic
-        static const bool no_small = getenv("IDE3D_HEAD_NO_SMALL") != nullptr;
+    {
         const int64_t hw = (int64_t)p.h * p.w_;
-        if (!no_small && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 && hw <= 256 && p.y_pitch == 0 && p.n <= 65535) {
+        if (head_small_applies(p)) {
             if (hw <= 64) hipLaunchKernelGGL((head_small_kernel<64, 32>), dim3(cdiv(p.cout, HS_RB), 1, p.n), dim3(HS_THREADS), 0, st_head, p, (int)hw);
             else          hipLaunchKernelGGL((head_small_kernel<256, 8>), dim3(cdiv(p.cout, HS_RB), cdiv((int)hw, 256), p.n), dim3(HS_THREADS), 0, st_head, p, (int)hw);
             IDE3D_CHECK_LAUNCH("modconv2d (small-map heads)");
@@ -2078,11 +2104,8 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         u32x4* wu = reinterpret_cast<u32x4*>(p.workspace);
         const int64_t items = (int64_t)p.n * cchunks * 2 * mt * 32;
         const int tiles = cdiv(p.h * p.w_, 32 * head_waves(mt));
-        // resident-weights form: whole K in LDS (K = 64 / 128 at <= 32 rows, K = 128 at 192 rows), >= 2 tiles of 32 pixels per wave
         const int hw_h = p.h * p.w_, wgs_img = kNumCU / p.n, tiles32 = hw_h / 32;
-        static const bool no_resident = getenv("IDE3D_HEAD_NO_RESIDENT") != nullptr;
-        const bool resident = !no_resident && kSpExclusive && p.cin % 16 == 0 && hw_h % 32 == 0 && wgs_img >= 1 && p.y_pitch == 0 &&
-                              ((mt == 1 && (cchunks == 4 || cchunks == 8)) || (mt == 6 && cchunks == 8)) && tiles32 >= 2 * wgs_img * 8;
+        const bool resident = head_resident_applies(p);
 #define IDE3D_HEAD_RES(P, M, C) hipLaunchKernelGGL((head_resident_kernel<P, M, C>), dim3(p.n * wgs_img), dim3(512), 0, st_head, p, wu, wgs_img, tiles32)
 #define IDE3D_HEAD(P, M) do { \
             hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
@@ -2156,6 +2179,45 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
                            pl.oh, pl.ow, (int64_t)(p.y_pitch > 0 ? p.y_pitch : pl.ow), nb_re, nb_ro, nb_ce);
     }
     IDE3D_CHECK_LAUNCH("modconv2d");
+    return IDE3D_OK;
+}
+
+// Host-only: which kernel family, tile and grid ide3d_modconv2d would launch for these parameters (pointers are not dereferenced; `x` only
+// for its alignment).  Same routing functions as the launch itself.
+extern "C" int ide3d_modconv_plan(const ide3d_modconv_params* pp, ide3d_modconv_plan_info* out) {
+    using namespace ide3d;
+    IDE3D_CHECK_ARG(pp != nullptr && out != nullptr, "modconv_plan: null argument");
+    const ide3d_modconv_params p = flatten_pointwise(*pp);
+    int rc = check_modconv(p);
+    if (rc) return rc;
+    *out = ide3d_modconv_plan_info{};
+    const int arith = resolve_arith(p.arith);
+    if (head_small_applies(p)) {
+        const int hw = p.h * p.w_;
+        out->kind = IDE3D_PLAN_HEAD_SMALL; out->tile_h = 1; out->tile_w = hw <= 64 ? 64 : 256; out->rows = HS_RB; out->waves = HS_THREADS / 64; out->split_k = 1;
+        out->workgroups = (int64_t)cdiv(p.cout, HS_RB) * (hw <= 64 ? 1 : cdiv(hw, 256)) * p.n;
+        return IDE3D_OK;
+    }
+    if (head_split_applies(p, arith)) {
+        const int mt = p.cout <= 32 ? 1 : 6;
+        out->rows = mt * 32; out->parts = arith == 3 ? 2 : 3; out->split_k = 1; out->tile_h = 1;
+        if (head_resident_applies(p)) { out->kind = IDE3D_PLAN_HEAD_RESIDENT; out->tile_w = 32; out->waves = 8; out->workgroups = (int64_t)p.n * (kNumCU / p.n); }
+        else { out->kind = IDE3D_PLAN_HEAD_SPLIT; out->waves = head_waves(mt); out->tile_w = 32 * out->waves; out->workgroups = (int64_t)p.n * cdiv(p.h * p.w_, out->tile_w); }
+        return IDE3D_OK;
+    }
+    int arith_eff = arith;
+    if (arith_eff == 16 && !p.x_amax) arith_eff = 6;
+    ConvPlan pl; plan_conv(p, pl, arith_eff);
+    const int64_t blocks = (int64_t)pl.g.mblocks * pl.g.tile_base[4] * pl.g.img_groups * pl.g.split_k;
+    out->tile_h = PHv[pl.tile]; out->tile_w = PWv[pl.tile]; out->images_per_tile = TIv[pl.tile];
+    out->rows = pl.bm; out->parts = pl.parts; out->f16 = pl.f16; out->split_k = pl.g.split_k; out->strip = pl.strip;
+    out->transposed_all_class = (pl.mode == MODE_TCONV3A);
+    if (pl.parts) {
+        const SpForm f = sp_form(pl);
+        out->kind = f.teams ? IDE3D_PLAN_SPLIT_TEAMS : IDE3D_PLAN_SPLIT; out->waves = f.teams ? 8 : f.waves; out->workgroups = f.teams ? blocks / 2 : blocks;
+    } else {
+        out->kind = IDE3D_PLAN_FP32; out->waves = (pl.tile == 8 || pl.tile == 9) ? 8 : 4; out->workgroups = blocks;
+    }
     return IDE3D_OK;
 }
 

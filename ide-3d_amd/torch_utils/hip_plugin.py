@@ -13,6 +13,7 @@ different arch, or a launch fails, a RuntimeError is raised.
 """
 
 import ctypes
+import math
 import os
 import threading
 import weakref
@@ -133,6 +134,18 @@ class _ModconvParams(ctypes.Structure):
     ]
 
 
+class _ModconvPlanInfo(ctypes.Structure):
+    """ide3d_modconv_plan_info (include/ide3d_hip.h): what ide3d_modconv2d would launch."""
+    _fields_ = [
+        ('kind', ctypes.c_int32), ('tile_h', ctypes.c_int32), ('tile_w', ctypes.c_int32), ('images_per_tile', ctypes.c_int32),
+        ('rows', ctypes.c_int32), ('waves', ctypes.c_int32), ('parts', ctypes.c_int32), ('f16', ctypes.c_int32),
+        ('split_k', ctypes.c_int32), ('strip', ctypes.c_int32), ('transposed_all_class', ctypes.c_int32), ('reserved', ctypes.c_int32),
+        ('workgroups', ctypes.c_int64),
+    ]
+
+
+PLAN_KINDS = ('fp32', 'split', 'split_teams', 'head_split', 'head_resident', 'head_small')     # IDE3D_PLAN_*
+
 STYLE_BATCH_MAX = 24        # IDE3D_STYLE_BATCH_MAX
 
 
@@ -234,6 +247,7 @@ def load():
             'ide3d_lattice_points': [ctypes.POINTER(_Lattice), i64, i64, vp, vp],
             'ide3d_density_lattice': [ctypes.POINTER(_RenderParams), ctypes.POINTER(_Lattice), i64, i64, vp, vp],
             'ide3d_modconv2d': [ctypes.POINTER(_ModconvParams), vp],
+            'ide3d_modconv_plan': [ctypes.POINTER(_ModconvParams), ctypes.POINTER(_ModconvPlanInfo)],
             'ide3d_modconv_workspace_bytes': [i32, i32, i32, i32, i32, i32, i32, i32],
             'ide3d_set_conv_arithmetic': [i32],
             'ide3d_get_conv_arithmetic': [],
@@ -261,7 +275,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
-    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
+    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_modconv_plan', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
     'ide3d_style_demod_batch', 'ide3d_fold_heads_batch',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
 )
@@ -889,6 +903,38 @@ class ModconvPlugin:
         _check(rc, 'modconv2d')
         ent[1], ent[2] = (None, None) if per_image else (w._version, weakref.ref(w))
         return y if pitch == ow else y[..., :ow]
+
+
+def modconv_plan(n, cin, cout, h, w, k=3, mode=0, per_image=False, arith=0, epilogue='conv', x_amax=False):
+    """Host-only (works without a GPU): the kernel family, tile and grid `modconv2d` would launch for this shape -> dict of the
+    ide3d_modconv_plan_info fields, `kind` as a name from PLAN_KINDS.  epilogue: 'conv' (noise, bias, lrelu, gain sqrt(2): the 3x3 layers),
+    'plain' (demodulation only: the up-sampling layers, whose FIR carries the rest) or 'head' (bias, clamp 256, linear).  x_amax: the
+    caller passes the producer's bound on |x| (what the f16x3 arithmetic needs)."""
+    p = _ModconvParams()
+    p.n, p.cin, p.cout, p.h, p.w_, p.k, p.mode = n, cin, cout, h, w, k, mode
+    p.arith = int(arith)
+    p.w_batch_stride = cout * cin * k * k if per_image else 0
+    dummy = 256                                  # non-null, 16-byte aligned, never dereferenced
+    p.x = p.w = p.y = dummy
+    if not per_image:
+        p.styles = p.dcoefs = dummy
+    if epilogue == 'conv':
+        p.noise, p.bias, p.noise_strength, p.act, p.alpha, p.gain, p.clamp = dummy, dummy, 1.0, 3, 0.2, math.sqrt(2.0), -1.0
+    elif epilogue == 'plain':
+        p.act, p.gain, p.clamp = 1, 1.0, -1.0
+    elif epilogue == 'head':
+        p.bias, p.act, p.gain, p.clamp = dummy, 1, 1.0, 256.0
+    else:
+        raise ValueError(epilogue)
+    if x_amax:
+        p.x_amax = dummy
+    info = _ModconvPlanInfo()
+    rc = load().ide3d_modconv_plan(ctypes.byref(p), ctypes.byref(info))       # (not a launch: stays out of CALLS)
+    if rc != 0:
+        raise RuntimeError(f'modconv_plan failed (code {rc}): ' + load().ide3d_last_error().decode('utf-8', 'replace'))
+    out = {name: getattr(info, name) for name, _ in _ModconvPlanInfo._fields_ if name != 'reserved'}
+    out['kind'] = PLAN_KINDS[info.kind]
+    return out
 
 
 _ARITH_NAMES = {'fp32': 1, 'bf16x3': 3, 'bf16x6': 6, 'f16x3': 16, 'default': 0}

@@ -378,6 +378,30 @@ int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t cout, int3
                                       int32_t per_image_weights);
 int ide3d_modconv2d(const ide3d_modconv_params* p, void* stream);
 
+/* Host-only planning query (no launch, no device access): the kernel family, tile and grid that ide3d_modconv2d would use for `p` in the
+ * arithmetic `p->arith` resolves to.  Pointers are not dereferenced (set `x_amax` non-null to plan the f16x3 launch; `x` counts for its
+ * alignment only).  For tests of the planner and for tooling; not part of the reference's interface. */
+enum { IDE3D_PLAN_FP32 = 0,          /* fp32-MFMA matrix loop (modconv_kernel) */
+       IDE3D_PLAN_SPLIT = 1,         /* split-bf16 / fp16 matrix loop (modconv_split_kernel) */
+       IDE3D_PLAN_SPLIT_TEAMS = 2,   /* the same, two 4-wave teams per workgroup */
+       IDE3D_PLAN_HEAD_SPLIT = 3,    /* per-image 1x1 heads, one tile per workgroup (head_split_kernel) */
+       IDE3D_PLAN_HEAD_RESIDENT = 4, /* per-image 1x1 heads, packed weights resident in LDS (head_resident_kernel) */
+       IDE3D_PLAN_HEAD_SMALL = 5 };  /* per-image 1x1 heads on maps of <= 256 pixels, fp32 FMAs (head_small_kernel) */
+typedef struct ide3d_modconv_plan_info {
+    int32_t kind;                    /* IDE3D_PLAN_* */
+    int32_t tile_h, tile_w;          /* pixels (transposed: grid positions) per workgroup / team */
+    int32_t images_per_tile;
+    int32_t rows;                    /* output channels per workgroup / team */
+    int32_t waves;                   /* per workgroup */
+    int32_t parts, f16;              /* pieces per operand (0: fp32 products), fp16 pieces */
+    int32_t split_k;                 /* > 1: partial sums + reduction launch */
+    int32_t strip;                   /* transposed: main kernel on the h x w grid + strip kernel */
+    int32_t transposed_all_class;
+    int32_t reserved;
+    int64_t workgroups;              /* of the main launch */
+} ide3d_modconv_plan_info;
+int ide3d_modconv_plan(const ide3d_modconv_params* p, ide3d_modconv_plan_info* out);
+
 /*
  * Arithmetic of the shared-weight 3x3 / transposed 3x3 layers on 16-pixel-wide tiles (everything else always runs on the
  * fp32 MFMA).  The reference computes these layers with ATen's fp32 convolution (conv2d_gradfix.py:35,40), or in fp16 for

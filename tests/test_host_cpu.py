@@ -50,7 +50,8 @@ def test_ctypes_structs_match_header_layout():
     src = open(os.path.join(ROOT, 'include', 'ide3d_hip.h')).read()
     for cname, cls in (('ide3d_upfirdn2d_params', hip_plugin._UpfirdnParams), ('ide3d_filtered_lrelu_params', hip_plugin._FlreluParams),
                        ('ide3d_render_params', hip_plugin._RenderParams), ('ide3d_modconv_params', hip_plugin._ModconvParams),
-                       ('ide3d_lattice', hip_plugin._Lattice), ('ide3d_style_job', hip_plugin._StyleJob), ('ide3d_fold_job', hip_plugin._FoldJob)):
+                       ('ide3d_lattice', hip_plugin._Lattice), ('ide3d_style_job', hip_plugin._StyleJob), ('ide3d_fold_job', hip_plugin._FoldJob),
+                       ('ide3d_modconv_plan_info', hip_plugin._ModconvPlanInfo)):
         body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, re.S).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []

@@ -1,0 +1,100 @@
+"""The launch planner of ide3d_modconv2d through its host-only query (include/ide3d_hip.h: ide3d_modconv_plan; no GPU needed): which kernel
+family, tile, split-K and grid the benchmark's layers get.  The rules these tests pin are the ones DESIGN.md section 4.3 measured: under
+exclusive residency (one workgroup per CU) a launch costs ceil(workgroups / 256) workgroup times, so the planner aims at whole rounds of the
+8-wave forms; the transposed layers run on the h x w position grid (strip plan) when their epilogue is the plain one; the heads go to the
+resident / small-map / one-tile kernels by shape.  GPU parity of every one of these forms: tests/test_gpu_conv_arith.py."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'ide-3d_amd'))
+
+from torch_utils import hip_plugin  # noqa: E402
+
+CU = 256
+pytestmark = pytest.mark.skipif(any(k.startswith(('IDE3D_MODCONV_', 'IDE3D_SP_', 'IDE3D_HEAD_')) for k in os.environ),
+                                reason='planner experiment switches are set in the environment')
+
+
+def plan(**kw):
+    kw.setdefault('n', 4)
+    kw.setdefault('arith', 6)
+    return hip_plugin.modconv_plan(**kw)
+
+
+@pytest.mark.parametrize('cin,res,tile,waves,split_k,wgs', [
+    (512, 4, (8, 16), 4, 16, 256), (512, 8, (8, 16), 4, 16, 256), (512, 16, (8, 16), 4, 8, 256), (512, 32, (16, 16), 8, 4, 256),
+    (512, 64, (16, 16), 8, 1, 256), (256, 128, (16, 16), 8, 1, 512), (128, 256, (16, 16), 8, 1, 1024)])
+def test_3x3_layers_of_the_backbone_run_whole_rounds_on_the_split_loop(cin, res, tile, waves, split_k, wgs):
+    p = plan(cin=cin, cout=cin, h=res, w=res)
+    assert p['kind'] == 'split' and p['parts'] == 3 and p['f16'] == 0 and p['rows'] == 128
+    assert (p['tile_h'], p['tile_w']) == tile and p['waves'] == waves and p['split_k'] == split_k
+    assert p['workgroups'] == wgs and wgs % CU == 0
+
+
+def test_64_row_3x3_layer_uses_the_32x16_tile():
+    p = plan(cin=64, cout=64, h=512, w=512)
+    assert (p['kind'], p['tile_h'], p['tile_w'], p['rows'], p['waves'], p['workgroups']) == ('split', 32, 16, 64, 8, 2048)
+    small = plan(cin=64, cout=64, h=64, w=64)                 # too few 32 x 16 tiles for two rounds: the 8 x 16 / 16 x 16 forms
+    assert small['tile_h'] != 32
+
+
+@pytest.mark.parametrize('cin,cout,res,tile,rows,wgs', [
+    (512, 512, 32, (8, 16), 64, 256), (512, 256, 64, (8, 16), 128, 256), (256, 128, 128, (8, 16), 128, 512), (128, 64, 256, (16, 16), 64, 1024),
+    (32, 128, 128, (8, 16), 128, 512)])
+def test_transposed_layers_run_the_strip_plan_at_whole_rounds(cin, cout, res, tile, rows, wgs):
+    p = plan(cin=cin, cout=cout, h=res, w=res, mode=2, epilogue='plain')
+    assert p['kind'] == 'split' and p['transposed_all_class'] == 1 and p['strip'] == 1 and p['split_k'] == 1 and p['waves'] == 8
+    assert (p['tile_h'], p['tile_w']) == tile and p['rows'] == rows and p['workgroups'] == wgs and wgs % CU == 0
+    # an epilogue with noise / bias / activation belongs to the main kernel: no strip kernel could finish it
+    q = plan(cin=cin, cout=cout, h=res, w=res, mode=2, epilogue='conv')
+    assert q['strip'] == 0
+
+
+def test_low_resolution_transposed_layers_use_two_team_workgroups_with_split_k():
+    for res, split_k, wgs in ((4, 8, 256), (8, 8, 384), (16, 3, 480)):
+        p = plan(cin=512, cout=512, h=res, w=res, mode=2, epilogue='plain')
+        assert (p['kind'], p['tile_h'], p['tile_w'], p['rows'], p['waves'], p['strip']) == ('split_teams', 4, 16, 64, 8, 0)
+        assert (p['split_k'], p['workgroups']) == (split_k, wgs)
+
+
+def test_arithmetic_selects_the_loop():
+    for mode, ep in ((0, 'conv'), (2, 'plain')):
+        p = plan(cin=128, cout=128, h=256, w=256, mode=mode, epilogue=ep, arith=1)
+        assert p['kind'] == 'fp32' and p['parts'] == 0                        # exact fp32 products: the fp32 matrix loop
+    assert plan(cin=128, cout=128, h=256, w=256, arith=3)['parts'] == 2       # bf16x3
+    no_bound = plan(cin=128, cout=128, h=256, w=256, arith=16)
+    assert (no_bound['parts'], no_bound['f16']) == (3, 0)                     # f16x3 without the producer's amax runs bf16x6
+    bound = plan(cin=128, cout=128, h=256, w=256, arith=16, x_amax=True)
+    assert (bound['parts'], bound['f16']) == (2, 1)
+    narrow = plan(cin=16, cout=128, h=256, w=256)                             # fewer than 3 K chunks: prologue + epilogue dominate
+    assert narrow['kind'] == 'fp32'
+
+
+@pytest.mark.parametrize('cin,cout,res,kind,wgs', [
+    (512, 192, 4, 'head_small', 192), (512, 192, 8, 'head_small', 192), (512, 192, 16, 'head_small', 192), (512, 192, 32, 'fp32', None),
+    (256, 192, 128, 'head_split', 256), (128, 192, 256, 'head_resident', 256), (128, 22, 256, 'head_resident', 256), (64, 22, 512, 'head_resident', 256)])
+def test_heads_are_routed_by_shape(cin, cout, res, kind, wgs):
+    p = plan(cin=cin, cout=cout, h=res, w=res, k=1, per_image=True, epilogue='head')
+    assert p['kind'] == kind
+    if wgs is not None:
+        assert p['workgroups'] == wgs
+    if kind == 'head_resident':
+        assert p['waves'] == 8 and p['rows'] == (32 if cout <= 32 else 192)
+
+
+def test_heads_in_exact_fp32_and_at_batch_1():
+    assert plan(cin=128, cout=192, h=256, w=256, k=1, per_image=True, epilogue='head', arith=1)['kind'] == 'fp32'
+    assert plan(cin=512, cout=192, h=8, w=8, k=1, per_image=True, epilogue='head', arith=1)['kind'] == 'head_small'     # fp32 FMAs: every arithmetic
+    # one image: 2048 tiles of 32 pixels for 2048 waves — fewer than two per wave, so the one-tile kernel
+    assert plan(n=1, cin=128, cout=192, h=256, w=256, k=1, per_image=True, epilogue='head')['kind'] == 'head_split'
+    assert plan(n=1, cin=64, cout=22, h=512, w=512, k=1, per_image=True, epilogue='head')['kind'] == 'head_resident'
+
+
+def test_bad_shapes_are_errors():
+    with pytest.raises(RuntimeError):
+        plan(cin=0, cout=8, h=4, w=4)
+    with pytest.raises(RuntimeError):
+        plan(cin=8, cout=8, h=4, w=4, k=5)
