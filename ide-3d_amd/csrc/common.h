@@ -20,6 +20,14 @@ constexpr int kNumXCD = 8;         // accelerator complex dies (private L2 each)
 
 void set_error(const char* fmt, ...);
 
+// Non-default compile-time knobs of the translation units that have any (each unit reports its own: scripts/micro/build_variant.sh recompiles
+// single files); '!' marks knobs that change results or drop a safety property.  Joined by ide3d_build_flags() (core.hip).
+const char* modconv_build_flags();
+const char* triplane_tile_build_flags();
+const char* raymarch_build_flags();
+#define IDE3D_STR_(x) #x
+#define IDE3D_STR(x) IDE3D_STR_(x)
+
 #define IDE3D_CHECK_ARG(cond, ...)                                   \
     do { if (!(cond)) { ide3d::set_error(__VA_ARGS__); return IDE3D_EINVAL; } } while (0)
 

@@ -16,5 +16,16 @@ void set_error(const char* fmt, ...) {
 }  // namespace ide3d
 
 extern "C" const char* ide3d_last_error(void) { return ide3d::g_err; }
-extern "C" int ide3d_abi_version(void) { return 5; }
+extern "C" int ide3d_abi_version(void) { return 6; }
 extern "C" const char* ide3d_build_arch(void) { return "gfx950"; }
+extern "C" const char* ide3d_build_flags(void) {
+    static char buf[512] = "";
+    static bool done = false;
+    if (!done) {
+        snprintf(buf, sizeof(buf), "%s%s%s", ide3d::modconv_build_flags(), ide3d::triplane_tile_build_flags(), ide3d::raymarch_build_flags());
+        const size_t n = strlen(buf);
+        if (n && buf[n - 1] == ' ') buf[n - 1] = 0;
+        done = true;
+    }
+    return buf;
+}

@@ -1859,7 +1859,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 // on the h x w grid of a strip plan (below) the 8-wave form may come out at whole rounds of ONE workgroup per CU where the (h + 1) x
                 // (w + 1) grid did not: 512 -> 256 in@64 = 256 workgroups of 8 x 16 positions x 128 rows, no split-K: 241 -> 211 us (f16x3 181 -> 149)
                 // against 512 four-wave workgroups of 4 x 16; 512 -> 512 in@32 (64 rows): 149 -> 141 against 256 two-team workgroups
-                const bool strip_ok = !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
+                const bool strip_ok = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
                 const int64_t b8s = (int64_t)pl.mblocks * cdiv(p.h, 8) * cdiv(p.w_, 16) * p.n, b4s = (int64_t)pl.mblocks * cdiv(p.h, 4) * cdiv(p.w_, 16) * p.n;
                 auto rounds = [](int64_t blocks) { return (blocks + kNumCU - 1) / kNumCU; };
                 if (pl.big == 1) {
@@ -1901,8 +1901,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     // Strip plan (tconv_strip_kernel): the all-class transposed convolution on the h x w grid when that saves tiles, the launch needs no split-K
     // either way (the reduction kernel would finish the strip's unwritten partials) and the epilogue is the plain one of the up-sampling
     // layers (demodulation only: noise / bias / activation follow the FIR).  IDE3D_MODCONV_NO_STRIP = the (h + 1) x (w + 1) grid everywhere.
+    // Shared weights only: the strip's pack / compute kernels read ONE weight tensor (per-image weights stay on the (h + 1) x (w + 1) grid).
     pl.strip = 0;
-    if (pl.mode == MODE_TCONV3A && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP")) {
+    if (pl.mode == MODE_TCONV3A && !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP")) {
         const int ph = PHv[pl.tile], pw = PWv[pl.tile];
         const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
         const int64_t groups = cdiv(p.n, TIv[pl.tile]);
@@ -2234,3 +2235,31 @@ extern "C" int ide3d_debug_mc(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ide3d::g_mc_dbg), sizeof(unsigned long long) * 256);
 }
 #endif
+
+namespace ide3d {
+const char* modconv_build_flags() {
+    return ""
+#ifdef IDE3D_SP_DBG
+        "!IDE3D_SP_DBG=" IDE3D_STR(IDE3D_SP_DBG) " "
+#endif
+#ifdef IDE3D_HEAD_DBG
+        "!IDE3D_HEAD_DBG=" IDE3D_STR(IDE3D_HEAD_DBG) " "
+#endif
+#ifdef IDE3D_F16_BF16MFMA
+        "!IDE3D_F16_BF16MFMA "
+#endif
+#ifdef IDE3D_SP_SHARED_SIMD
+        "!IDE3D_SP_SHARED_SIMD "
+#endif
+#ifdef IDE3D_F16_NO_FMA_MIX
+        "IDE3D_F16_NO_FMA_MIX "
+#endif
+#ifdef IDE3D_MC_TRACE
+        "IDE3D_MC_TRACE "
+#endif
+#if IDE3D_SP_AHEAD != 1
+        "IDE3D_SP_AHEAD=" IDE3D_STR(IDE3D_SP_AHEAD) " "
+#endif
+        ;
+}
+}  // namespace ide3d

@@ -1021,3 +1021,13 @@ extern "C" int ide3d_density_lattice(const ide3d_render_params* pp, const ide3d_
     set_error("density_lattice: no fused kernel for C=%d hidden=%d", p.C, p.hidden);
     return IDE3D_ENOKERNEL;
 }
+
+namespace ide3d {
+const char* raymarch_build_flags() {
+    return ""
+#ifdef IDE3D_SPLIT_NO_DOT2
+        "IDE3D_SPLIT_NO_DOT2 "
+#endif
+        ;
+}
+}  // namespace ide3d

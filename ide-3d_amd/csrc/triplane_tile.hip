@@ -797,3 +797,13 @@ extern "C" int ide3d_debug_tt_pc(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ide3d::g_pc_dbg), sizeof(unsigned long long) * 3 * 32 * 8);
 }
 #endif
+
+namespace ide3d {
+const char* triplane_tile_build_flags() {
+    return ""
+#ifdef IDE3D_TT_TRACE
+        "IDE3D_TT_TRACE "
+#endif
+        ;
+}
+}  // namespace ide3d

@@ -21,7 +21,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 5
+_ABI_VERSION = 6
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -227,6 +227,15 @@ def load():
         lib.ide3d_build_arch.restype = ctypes.c_char_p
         if lib.ide3d_abi_version() != _ABI_VERSION:
             raise RuntimeError(f'{path}: ABI version {lib.ide3d_abi_version()} != expected {_ABI_VERSION}; rebuild')
+        # a library built with timing-only experiment knobs (wrong results by design) or without exclusive residency must never be
+        # mistaken for the product: it loads only when the experimenter says so
+        lib.ide3d_build_flags.restype = ctypes.c_char_p
+        lib.ide3d_build_flags.argtypes = []
+        flags = lib.ide3d_build_flags().decode('ascii', 'replace').split()
+        unsafe = [f for f in flags if f.startswith('!')]
+        if unsafe and os.environ.get('IDE3D_ALLOW_EXPERIMENT_BUILD') != '1':
+            raise RuntimeError(f'{path} was built with experiment knobs that change results or drop a safety property ({" ".join(unsafe)}); '
+                               'rebuild without EXTRA=..., or set IDE3D_ALLOW_EXPERIMENT_BUILD=1 for timing experiments')
         protos = {
             'ide3d_bias_act': [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32, f32, f32, i64, i64, i64, vp],
             'ide3d_upfirdn2d': [ctypes.POINTER(_UpfirdnParams), vp],
@@ -271,7 +280,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = (
-    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
+    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_build_flags', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',

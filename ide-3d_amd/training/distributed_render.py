@@ -119,6 +119,7 @@ def render_items(G, seeds: Sequence[int], yaws: Sequence[float], items: Sequence
     cams = {p: triplane.camera_label(yaws[p], device=device) for p in sorted({p for _, p in items})}
     palette = palette_tensor(G.synthesis.seg_channels, device)
     ws_cache, plane_cache, out = {}, {}, []
+    plane_buf, buf_seed = None, None
     for start in range(0, len(items), batch):
         chunk = items[start:start + batch]
         for s, _ in chunk:
@@ -126,13 +127,25 @@ def render_items(G, seeds: Sequence[int], yaws: Sequence[float], items: Sequence
                 z = torch.from_numpy(np.random.RandomState(seeds[s]).randn(1, G.z_dim)).to(device)
                 ws_cache[s] = G.mapping(z, cond, truncation_psi=truncation_psi)
                 if cache_backbone:
-                    voxel_ws, _ = G.synthesis.split_ws(ws_cache[s])
-                    plane_cache[s] = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode)
+                    plane_cache[s] = G.synthesis.planes(ws_cache[s], noise_mode=noise_mode)
         ws = torch.cat([ws_cache[s] for s, _ in chunk])
         c = torch.cat([cams[p] for _, p in chunk])
         planes = None
         if cache_backbone:
-            planes = (torch.cat([plane_cache[s][0] for s, _ in chunk]), torch.cat([plane_cache[s][1] for s, _ in chunk]))
+            # the batch's tri-planes live in ONE pair of buffers for the whole job: a row is rewritten only when its seed changes (all
+            # poses of a seed are consecutive items), and `G.synthesis` sees the same addresses in every call — it reads cached
+            # tri-planes in place, so its captured pass (training/graph_cache.py) is keyed on them
+            if plane_buf is None:
+                like = plane_cache[chunk[0][0]]
+                plane_buf = tuple(torch.empty([batch, *t.shape[1:]], dtype=t.dtype, device=t.device).contiguous(memory_format=torch.channels_last)
+                                  for t in like)
+                buf_seed = [None] * batch
+            for j, (s, _) in enumerate(chunk):
+                if buf_seed[j] != s:
+                    for k in range(2):
+                        plane_buf[k][j].copy_(plane_cache[s][k][0])
+                    buf_seed[j] = s
+            planes = (plane_buf[0][:len(chunk)], plane_buf[1][:len(chunk)])
         jit = None
         if jitter_seed is not None:      # reproducible stratified jitter (same draws whatever the sharding)
             g = G.synthesis

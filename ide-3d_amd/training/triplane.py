@@ -24,6 +24,7 @@ Every architecture number is a constructor argument (`GeneratorSpec`): the real 
 parity statements are "this path vs the CPU oracle with the same spec and weights".
 """
 
+import contextlib
 import dataclasses
 import math
 import os
@@ -36,6 +37,7 @@ from dnnlib import util
 from torch_utils import misc
 from torch_utils import persistence
 from torch_utils.ops import bias_act
+from training import graph_cache
 from training import networks
 from training import volumetric_rendering as vr
 
@@ -324,6 +326,42 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
             x_v, img_v, seg_v = getattr(self, f'vb{res}')(x_v, img_v, cur_ws, condition_img=seg_v, **block_kwargs)
         return img_v, seg_v
 
+    @contextlib.contextmanager
+    def _pass_scope(self, ws, voxel_and_sr):
+        """What surrounds the launches of one pass: the amax arena of the f16x3 arithmetic and — only while a hipGraph is being
+        captured — the style / demodulation / head-folding launches of the given blocks on a side stream (they depend only on ws).
+        With eager launches the host is the bottleneck and 43 extra events cost more than the overlap returns (measured: -11 % on
+        the eager video driver, +2.4 % on the graphed renderer)."""
+        voxel, sr = voxel_and_sr
+        prefetch = (getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled()
+                    and torch.cuda.is_current_stream_capturing() and not os.environ.get('IDE3D_NO_STYLE_PREFETCH'))
+        side = None
+        arena = networks.amax_arena(ws.shape[0], ws.device)
+        arena.__enter__()
+        try:
+            if prefetch:
+                side = networks.side_stream(ws.device)
+                todo = [(getattr(self, f'vb{r}'), w) for r, w in voxel] + [(getattr(self, f'b{r}'), w) for r, w in sr]
+                networks.prefetch_styles(todo, side)
+            yield
+        finally:
+            arena.__exit__(None, None, None)
+            if side is not None:
+                networks.finish_prefetch(side)      # joins the side stream and drops the table even when a layer raised
+
+    def planes(self, ws, noise_mode='const', force_fp32=False):
+        """ws [N, num_ws, w_dim] -> (texture tri-plane, semantic tri-plane): `split_ws` + `backbone` as one call, so that drivers which
+        cache the pose-independent tri-planes per seed (training/distributed_render.py, training/video_render.py) get the captured-graph
+        rate for it too (training/graph_cache.py; fresh tensors per call)."""
+        def impl(ws_, _c, _jitter, _planes):
+            voxel_ws, _ = self.split_ws(ws_)
+            with self._pass_scope(ws_, (list(zip(self.voxel_block_resolutions, voxel_ws)), [])):
+                return self.backbone(voxel_ws, noise_mode=noise_mode, force_fp32=force_fp32)
+
+        if torch.is_tensor(ws) and ws.is_cuda:
+            return graph_cache.run(self, impl, ws, None, {}, noise_mode, (), force_fp32, False, None, {}, kind='backbone')
+        return impl(ws, None, False, None)
+
     def superres(self, feat, block_ws, **block_kwargs):
         """[N, feat+seg, R, R] composited features -> (img, seg) at full resolution."""
         fc = self.spec.feature_channels
@@ -344,26 +382,29 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
 
     def forward(self, ws, c=None, render_params=None, noise_mode='const', return_seg=False, return_raw=False,
                 return_dict=False, force_fp32=False, cond_img=None, ray_jitter=None, cached_planes=None, **unused):
-        """ws [N, num_ws, w_dim], c [N, 25] = flattened cam2world (16) + intrinsics (9)."""
+        """ws [N, num_ws, w_dim], c [N, 25] = flattened cam2world (16) + intrinsics (9).
+
+        On the GPU in inference a repeated call signature is captured into a hipGraph and replayed (training/graph_cache.py: the
+        reference's per-image driver loops are bound by the host's ~80 launches per pass otherwise); outputs are fresh tensors
+        either way.  `self.auto_graph = False`, `IDE3D_AUTO_GRAPH=0` or a forward hook anywhere in the tree keep every call eager."""
         assert c is not None, 'synthesis needs the 25-D camera label c'
         render_params = dict(render_params or {})
+        flags = (bool(return_seg), bool(return_raw), bool(return_dict))
+
+        def impl(ws_, c_, jitter_, planes_):
+            return self._forward_impl(ws_, c_, render_params, noise_mode, flags, force_fp32, jitter_, planes_)
+
+        if torch.is_tensor(ws) and ws.is_cuda:
+            return graph_cache.run(self, impl, ws, c, render_params, noise_mode, flags, force_fp32, ray_jitter, cached_planes, unused)
+        return impl(ws, c, ray_jitter, cached_planes)
+
+    def _forward_impl(self, ws, c, render_params, noise_mode, flags, force_fp32, ray_jitter, cached_planes):
+        """The pass itself, launch by launch (what `forward` runs eagerly, and what a capture records)."""
+        return_seg, return_raw, return_dict = flags
         voxel_ws, block_ws = self.split_ws(ws)
         # `force_fp32` (viz/renderer.py:439 passes it) reaches the blocks; without fp16 blocks in the spec it changes nothing
         block_kwargs = dict(noise_mode=noise_mode, force_fp32=force_fp32)
-        # only while a hipGraph is being captured: with eager launches the host is the bottleneck and 43 extra events cost more
-        # than the overlap returns (measured: -11 % on the eager video driver, +2.4 % on the graphed renderer)
-        prefetch = (getattr(self, 'style_prefetch', True) and ws.is_cuda and not torch.is_grad_enabled()
-                    and torch.cuda.is_current_stream_capturing() and not os.environ.get('IDE3D_NO_STYLE_PREFETCH'))
-        side = None
-        arena = networks.amax_arena(ws.shape[0], ws.device)
-        arena.__enter__()
-        try:
-            if prefetch:
-                # all style / demodulation / head-folding launches of this pass go to a side stream (they depend only on ws)
-                side = networks.side_stream(ws.device)
-                todo = [] if cached_planes is not None else [(getattr(self, f'vb{r}'), w) for r, w in zip(self.voxel_block_resolutions, voxel_ws)]
-                todo += [(getattr(self, f'b{r}'), w) for r, w in zip(self.block_resolutions, block_ws)]
-                networks.prefetch_styles(todo, side)
+        with self._pass_scope(ws, ([] if cached_planes is not None else list(zip(self.voxel_block_resolutions, voxel_ws)), list(zip(self.block_resolutions, block_ws)))):
             if cached_planes is not None:
                 img_v, seg_v = cached_planes
             else:
@@ -375,10 +416,6 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
                 nerf_noise=render_params.get('nerf_noise', 0.0), jitter=ray_jitter,
                 hierarchical=render_params.get('hierarchical'), importance_u=render_params.get('importance_u'))
             img, seg = self.superres(feat, block_ws, **block_kwargs)
-        finally:
-            arena.__exit__(None, None, None)
-            if side is not None:
-                networks.finish_prefetch(side)      # joins the side stream and drops the table even when a layer raised
         img_raw = feat[:, :self.img_channels]
         if return_dict:
             return dict(image=img, image_seg=seg, image_raw=img_raw, image_depth=depth, planes=(img_v, seg_v))
@@ -495,7 +532,7 @@ class GraphedRenderer:
         # kernel's barrier counter) from workspaces owned by THIS object (hip_plugin.workspace_scope), not by a stream handle that
         # another graph or an eager caller may be handed as well; the replays reuse the copies packed during warm-up.
         scope = self._scope(device)
-        with torch.cuda.stream(stream), torch.no_grad(), scope:
+        with torch.cuda.stream(stream), torch.no_grad(), scope, graph_cache.disabled():      # this object IS the capture: no automatic one inside it
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(device).wait_stream(stream)

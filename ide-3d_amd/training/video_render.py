@@ -84,8 +84,7 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
     static = cache_static_planes and num_keyframes == 1 and bool(torch.allclose(ws_frames, ws_frames[:, :1].expand_as(ws_frames), atol=1e-5))
     planes = None
     if static:
-        voxel_ws, _ = G.synthesis.split_ws(ws_frames[:, 0])
-        planes = G.synthesis.backbone(voxel_ws, noise_mode=noise_mode)
+        planes = G.synthesis.planes(ws_frames[:, 0], noise_mode=noise_mode)
     palette = dr.palette_tensor(G.synthesis.seg_channels, device)
     for frame_idx in range(total):
         c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)

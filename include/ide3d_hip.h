@@ -37,6 +37,11 @@ const char* ide3d_last_error(void);
 /* ABI version (bumped on any signature change) and the gfx arch string the library was built for. */
 int         ide3d_abi_version(void);
 const char* ide3d_build_arch(void);
+/* ABI 6.  Space-separated list of the non-default compile-time knobs this binary was built with ("" for a release build; `make EXTRA=-D...`,
+ * scripts/micro/build_variant.sh).  A knob that changes RESULTS or drops a safety property — the timing-only experiments IDE3D_SP_DBG /
+ * IDE3D_HEAD_DBG / IDE3D_F16_BF16MFMA (wrong values by design) and IDE3D_SP_SHARED_SIMD (no exclusive residency) — is listed
+ * with a leading '!'; the host side (`hip_plugin.load()`) refuses such a library unless IDE3D_ALLOW_EXPERIMENT_BUILD=1 is set. */
+const char* ide3d_build_flags(void);
 
 /* ---- bias_act ------------------------------------------------------------------------- */
 /*

@@ -559,6 +559,28 @@ def test_modconv2d_transposed_against_conv_transpose2d(gpu_device, n, cin, cout,
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', [(4, 128, 128, 128, 128), (3, 64, 64, 32, 32), (2, 16, 24, 9, 6)])
+def test_modconv2d_transposed_per_image_weights(gpu_device, n, cin, cout, h, w):
+    """mode 2 with PER-IMAGE weights [n, cout, cin, 3, 3] (styles folded in by the caller): every image is convolved with ITS weights in
+    the whole output, including output row 2h and column 2w (the strip plan — `tconv_strip_kernel` reads one shared weight tensor — must not
+    be chosen for such a launch: ADVICE r4; `modconv_plan` agrees)."""
+    from torch_utils import hip_plugin
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(n, cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    d = torch.rand(n, cout, generator=g) + 0.5
+    ref = torch.stack([torch.nn.functional.conv_transpose2d(x[i:i + 1].double(), wt[i].transpose(0, 1).double(), stride=2)[0] for i in range(n)])
+    ref = ref * d.double()[:, :, None, None]
+    plan = hip_plugin.modconv_plan(n, cin, cout, h, w, mode=2, per_image=True, epilogue='plain')
+    assert not plan['strip'], plan
+    y = hip_plugin.ModconvPlugin.modconv2d(x.to(gpu_device), wt.to(gpu_device), None, d.to(gpu_device), None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2)
+    assert y.shape == (n, cout, 2 * h + 1, 2 * w + 1)
+    scale = float(ref.abs().max())
+    for name, sl in (('interior', (slice(None), slice(None), slice(0, 2 * h), slice(0, 2 * w))), ('last row', (slice(None), slice(None), slice(2 * h, None))),
+                     ('last column', (slice(None), slice(None), slice(None), slice(2 * w, None)))):
+        assert_close(y[sl], ref[sl].float(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), what=f'per-image tconv {n, cin, cout, h, w}: {name}')
+
+
 def test_modconv2d_low_resolution_split_k(gpu_device):
     """512 -> 512 channels at 4x4 / 8x8 / 16x16 / 32x32, batch 4: split-K path + image-batched pixel tiles."""
     from torch_utils import hip_plugin

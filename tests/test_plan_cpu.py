@@ -98,3 +98,13 @@ def test_bad_shapes_are_errors():
         plan(cin=0, cout=8, h=4, w=4)
     with pytest.raises(RuntimeError):
         plan(cin=8, cout=8, h=4, w=4, k=5)
+
+
+def test_per_image_transposed_layers_never_take_the_strip_plan():
+    """`tconv_strip_kernel` reads ONE weight tensor; a launch with per-image weights [n, cout, cin, 3, 3] must stay on the
+    (h + 1) x (w + 1) grid in every arithmetic (the GPU counterpart: tests/test_gpu_ops.py::test_modconv2d_transposed_per_image_weights)."""
+    for arith in (0, 1, 6, 16):
+        for shape in ((4, 128, 128, 128, 128), (4, 512, 256, 64, 64), (1, 64, 64, 32, 32)):
+            p = hip_plugin.modconv_plan(*shape, mode=2, per_image=True, arith=arith, epilogue='plain')
+            assert p['strip'] == 0 and p['kind'] == 'fp32', (arith, shape, p)
+    assert hip_plugin.modconv_plan(4, 128, 128, 128, 128, mode=2, per_image=False, epilogue='plain')['strip'] == 1
