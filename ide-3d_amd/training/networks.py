@@ -15,6 +15,7 @@ with the FIR, the demodulation/noise and the bias-activation on HIP kernels.  Wi
 evaluate the same mathematics through differentiable ops.
 """
 
+import math
 import weakref
 
 import numpy as np
@@ -613,7 +614,7 @@ class MappingNetwork(torch.nn.Module):
         layers = [getattr(self, f'fc{i}') for i in range(self.num_layers)]
         embed = self.embed if self.c_dim > 0 else None
         if any(l.activation != 'lrelu' or l.weight.dtype != torch.float32 or l.bias_gain != layers[0].bias_gain
-               or not np.isclose(l.weight_gain * np.sqrt(l.weight.shape[1]), l.bias_gain, rtol=1e-6) for l in layers):      # one lr_multiplier
+               or not math.isclose(l.weight_gain * math.sqrt(l.weight.shape[1]), l.bias_gain, rel_tol=1e-6) for l in layers):      # one lr_multiplier
             return None
         if embed is not None and (embed.activation != 'linear' or c is None):
             return None

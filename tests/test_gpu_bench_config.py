@@ -76,6 +76,35 @@ def _rel_m(actual, expected, tol, what, key=None):
     assert err <= tol * scale, f'{what}: max abs err {err:.3e} > {tol} * scale {scale:.3e} (rel {err / scale:.2e})'
 
 
+FRAME_TOL = 2e-5       # the float tolerance of the full-frame comparisons below, of the tensor's scale
+
+
+def _frame_u8_check(got, img_ref, seg_ref, what, tol=FRAME_TOL):
+    """uint8 frame `got` [H, 2W, 3] (RGB | palette[argmax seg]) against the ORACLE'S FLOATS img_ref [1, 3, H, W], seg_ref [1, K, H, W]:
+      * every RGB byte within 1 LSB of the oracle's byte, and a 1-LSB difference ONLY where the oracle's own value x = img * 127.5 + 128
+        lies within tol * scale * 127.5 of the integer it truncates at (two float images that agree to tol * scale can only straddle a
+        truncation boundary that close to one of them);
+      * a different class colour ONLY where the oracle's two largest logits are closer than 2 * tol * scale.
+    With the measured float error (4e-6 of scale) anything else is a defect, not rounding."""
+    img_ref = torch.as_tensor(img_ref).detach().cpu().float(); seg_ref = torch.as_tensor(seg_ref).detach().cpu().float()
+    h, w = img_ref.shape[-2:]
+    x = (img_ref[0] * 127.5 + 128).permute(1, 2, 0).numpy()
+    want = np.clip(x, 0, 255).astype(np.uint8)
+    d = got[:, :w].astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 1, f'{what}: RGB byte off by {np.abs(d).max()} LSB'
+    margin = tol * float(img_ref.abs().max()) * 127.5
+    unexplained = (d != 0) & (np.abs(x - np.round(x)) > margin)
+    assert not unexplained.any(), (f'{what}: {int(unexplained.sum())} RGB bytes differ where the oracle is more than {margin:.2e} from a truncation boundary '
+                                   f'({int((d != 0).sum())} 1-LSB sites in all)')
+    top2 = torch.topk(seg_ref[0], 2, dim=0).values.numpy()
+    gap = top2[0] - top2[1]
+    want_col = oracle_ops.frame_u8(img_ref, seg_ref)[0][:, w:]
+    flips = (got[:, w:] != want_col).any(axis=-1)
+    unexplained = flips & (gap > 2 * tol * float(seg_ref.abs().max()))
+    assert not unexplained.any(), f'{what}: {int(unexplained.sum())} class flips where the oracle\'s top-2 logit gap exceeds 2 * tol * scale ({int(flips.sum())} flips in all)'
+    return int((d != 0).sum()), int(flips.sum())
+
+
 def _config2_inputs():
     from training import triplane
     B = 4
@@ -139,12 +168,9 @@ def test_config2_batch4_graph_replay_vs_oracle(bench_generator, config2_oracle, 
         _rel_m(out['image_raw'][i:i + 1], ref['image_raw'], 1e-4, f'{arith}: raw 64x64 image [{i}]', f'{arith}/image_raw')
         _rel_m(img_g[i:i + 1], ref['image'], 2e-5, f'{arith}: image 512 [{i}]', f'{arith}/image')
         _rel_m(seg_g[i:i + 1], ref['image_seg'], 2e-5, f'{arith}: seg 512 [{i}]', f'{arith}/image_seg')
-        want = ref['frame']
-        got = frames_gpu[i]
-        rgb_off = np.abs(got[:, :512].astype(np.int32) - want[:, :512].astype(np.int32)) > 1
-        assert rgb_off.mean() < 5e-3, f'uint8 RGB frame [{i}]: {rgb_off.mean():.4f} of the values differ by more than 1 LSB'
-        flips = (got[:, 512:] != want[:, 512:]).any(axis=-1)
-        assert flips.mean() < 5e-3, f'seg colour frame [{i}]: {flips.mean():.4f} argmax flips'
+        lsb, flips = _frame_u8_check(frames_gpu[i], ref['image'], ref['image_seg'], f'{arith}: uint8 frame [{i}]')
+        MEASURED[f'{arith}/frame_1lsb_sites'] = MEASURED.get(f'{arith}/frame_1lsb_sites', 0) + lsb
+        MEASURED[f'{arith}/frame_class_flips'] = MEASURED.get(f'{arith}/frame_class_flips', 0) + flips
 
 
 def test_dropin_batch1_eager_equals_graphed_batch4_row(bench_generator, gpu_device):
@@ -237,15 +263,12 @@ def test_config3_full_size_grid_frame_vs_oracle(bench_generator, gpu_device, ora
         for k in range(4):
             ws_o = ogen.mapping(sd, osp, zs[k:k + 1], c_front, truncation_psi=psi, truncation_cutoff=cutoff, ops=fast_ops)
             ref = ogen.synthesis(sd, osp, ws_o, c, jitter=None, ops=fast_ops)
-            cells.append(oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0])
-        want = np.stack(cells).reshape(2, 2, 512, 1024, 3).transpose(0, 2, 1, 3, 4).reshape(1024, 2048, 3)
+            cells.append((ref['image'], ref['image_seg']))
         got = frames[idx]
-        assert got.shape == want.shape == (1024, 2048, 3)
-        is_seg = (np.arange(2048) % 1024) >= 512
-        rgb_off = np.abs(got[:, ~is_seg].astype(np.int32) - want[:, ~is_seg].astype(np.int32)) > 1
-        assert rgb_off.mean() < 5e-3, f'frame {idx}: {rgb_off.mean():.4f} of the RGB values differ by more than 1 LSB'
-        flips = (got[:, is_seg] != want[:, is_seg]).any(axis=-1)
-        assert flips.mean() < 5e-3, f'frame {idx}: {flips.mean():.4f} seg argmax flips'
+        assert got.shape == (1024, 2048, 3)
+        for k, (img_ref, seg_ref) in enumerate(cells):                 # cell k of the 2x2 grid: row k // 2, column k % 2 (layout_grid, gen_videos.py:24-38)
+            cell = got[(k // 2) * 512:(k // 2 + 1) * 512, (k % 2) * 1024:(k % 2 + 1) * 1024]
+            _frame_u8_check(cell, img_ref, seg_ref, f'frame {idx}, cell {k}')
 
 
 def test_config4_sharded_items_full_size_vs_oracle(bench_generator, gpu_device, oracle_threads):
@@ -267,20 +290,19 @@ def test_config4_sharded_items_full_size_vs_oracle(bench_generator, gpu_device, 
         for pi, yaw in enumerate(yaws):
             jit = torch.rand([64 * 64, 96], generator=torch.Generator().manual_seed(77 + dr.item_index(si, pi, len(yaws))))[None]
             ref = ogen.synthesis(sd, osp, ws_o, triplane.camera_label(yaw), jitter=jit, ops=fast_ops)
-            want.append(oracle_ops.frame_u8(ref['image'], ref['image_seg'])[0])
-    want = np.stack(want)
+            want.append((ref['image'], ref['image_seg']))
+    from training import graph_cache
+    passes = lambda: graph_cache.STATS['eager'] + graph_cache.STATS['replay'] + sum(v for k, v in graph_cache.STATS.items() if k.startswith('ineligible'))
     try:
         for arith in ('fp32', 'f16x3'):
             hip_plugin.conv_arithmetic(arith)
-            before = _calls('render_rays'), _calls('frame_u8')
+            before = _calls('render_rays'), _calls('frame_u8'), passes()
             got = dr.render_grid_sharded(G, seeds, yaws, gpu_device, rank=0, world=1, batch=4, jitter_seed=77).cpu().numpy()
-            assert _calls('render_rays') - before[0] == 4 and _calls('frame_u8') - before[1] == 4      # 16 items in batches of 4
-            assert got.shape == want.shape == (16, 512, 1024, 3)
+            # 16 items in batches of 4: four `G.synthesis` passes (eager, then captured and replayed: training/graph_cache.py), four frame launches
+            assert passes() - before[2] == 4 + 2 and _calls('frame_u8') - before[1] == 4 and _calls('render_rays') > before[0]       # + the two seeds' `planes` calls
+            assert got.shape == (16, 512, 1024, 3)
             for i in range(16):
-                rgb_off = np.abs(got[i, :, :512].astype(np.int32) - want[i, :, :512].astype(np.int32)) > 1
-                assert rgb_off.mean() < 5e-3, f'{arith}, item {i}: {rgb_off.mean():.4f} of the RGB values differ by more than 1 LSB'
-                flips = (got[i, :, 512:] != want[i, :, 512:]).any(axis=-1)
-                assert flips.mean() < 5e-3, f'{arith}, item {i}: {flips.mean():.4f} seg argmax flips'
+                _frame_u8_check(got[i], want[i][0], want[i][1], f'{arith}, item {i}')
     finally:
         hip_plugin.conv_arithmetic('default')
 

@@ -96,8 +96,17 @@ def test_forward_hook_anywhere_in_the_tree_keeps_the_call_eager(G, gpu_device):
     finally:
         h.remove()
     for _ in range(3):
-        G.synthesis(ws, c=c, ray_jitter=False)
+        want = G.synthesis(ws, c=c, ray_jitter=False)
     assert graph_cache.stats(G.synthesis)['graphs'] == 1
+    # a hook registered AFTER the pass was captured: the (optimistic) replay is thrown away, the eager pass runs — and calls the hook, once
+    h = G.synthesis.vb8.register_forward_hook(lambda m, i, o: seen.append('vb8'))
+    try:
+        n0, d0 = _launches(), graph_cache.STATS['replay_discarded']
+        got = G.synthesis(ws, c=c, ray_jitter=False)
+        assert _launches() > n0 and seen[-1] == 'vb8' and seen.count('vb8') == 1 and graph_cache.STATS['replay_discarded'] == d0 + 1
+        assert torch.equal(got, want)
+    finally:
+        h.remove()
 
 
 def test_weights_edited_in_place_are_seen_and_the_pass_is_captured_again(G, gpu_device):
