@@ -41,6 +41,10 @@ __device__ unsigned long long g_tt_dbg[256];
 #define IDE3D_TS(k)
 #endif
 
+#ifdef IDE3D_PC_EXP
+#define IDE3D_PC_EXP_DEFINED_EARLY IDE3D_PC_EXP
+#endif
+
 namespace {
 
 constexpr int TT_EDGE = 8;                    // ray tile edge
@@ -48,6 +52,7 @@ constexpr int TT_DS = 4;                      // depth steps per chunk
 constexpr int TT_C = 32;                      // channels per plane (line = 128 B)
 constexpr int TT_LINE = TT_C * 4;             // bytes
 constexpr int TT_CAP = 504;                   // LDS lines: 504 * 128 + 256 * 64 + 128 = 81 024 B -> 2 workgroups / CU
+constexpr int PC_CAP = 504;                   // producer / consumer kernel, lines per buffer: 2 x (504 x 128 + 16 KB tap table) + 512 B = 162 304 B of the 160 KB
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -175,6 +180,9 @@ template <bool STAGED>
 __device__ __forceinline__ void load_lines(const TileArgs& p, const unsigned char* s_lines, __amdgpu_buffer_rsrc_t rsrc,
                                            unsigned pitch, unsigned e, unsigned ch_bytes, f32x4_t (&v)[4]) {
     if (STAGED) {
+#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 4)
+        e = (e & ~128u) | ((((unsigned)threadIdx.x >> 4) & 1u) << 7);        // slot >> 1 picks the bank half
+#endif
         const unsigned char* l0 = s_lines + (e | ch_bytes);
         const unsigned char* l1 = l0 + pitch;
         v[0] = *reinterpret_cast<const f32x4_t*>(l0);
@@ -227,6 +235,9 @@ __device__ __forceinline__ void blend_chunk(const TileArgs& p, const unsigned ch
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const size_t d = (size_t)((unsigned)(r >> 2) * (unsigned)p.rays_w + (unsigned)(r & 3) * 2u) * (unsigned)p.steps * TT_C;
+#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 8)
+        if (res[r][0] == 1.2345e-30f)
+#endif
         __builtin_nontemporal_store(res[r], reinterpret_cast<f32x4_t*>(o_lane + d));
     }
 }
@@ -312,9 +323,44 @@ __device__ __forceinline__ int stage_issue_buf(const TileArgs& p, __amdgpu_buffe
     return ns;
 }
 
+// The same segments by LDS-DMA (`buffer_load_dwordx4 ... lds`: per-lane buffer offsets, the wave's 1 KB lands at M0 + 16 * lane): no
+// registers, no ds_write, all three planes of a chunk in flight at once.  Bounded like stage_issue_buf (zeros beyond the plane group).
+template <int NSEG, int NW = 4>       // NW: waves that share a region's segments (segment s belongs to wave s % NW)
+__device__ __forceinline__ void stage_dma(const TileArgs& p, __amdgpu_buffer_rsrc_t rsrc, const Region& R, int pl, unsigned img_bytes,
+                                          int wid, int slot, unsigned ch_bytes, unsigned char* s_lines) {
+    const unsigned nseg8 = (R.bw * R.bh + 7u) >> 3;
+    const int ns = (nseg8 > (unsigned)wid) ? (int)((nseg8 - (unsigned)wid + (unsigned)(NW - 1)) / (unsigned)NW) : 0;
+    const unsigned sWb = (unsigned)p.sW * 4u, sHb = (unsigned)p.sH * 4u;
+    const unsigned q = (unsigned)wid * 8u + (unsigned)slot;
+    const unsigned ry = (unsigned)(((float)q + 0.5f) * (1.0f / (float)R.bw));
+    unsigned rx = q - ry * R.bw;
+    unsigned goff = img_bytes + (unsigned)pl * TT_LINE + (R.y0 - 1u + ry) * sHb + (R.x0 - 1u + rx) * sWb + ch_bytes;
+    constexpr unsigned STEP = 8u * NW;                                    // lines between two segments of one wave
+    const unsigned a = STEP / R.bw, b = STEP - a * R.bw;
+    const unsigned inc = a * sHb + b * sWb, inc_wrap = inc + sHb - R.bw * sWb;
+    unsigned char* dst = s_lines + (R.base + (unsigned)wid * 8u) * TT_LINE;
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) {
+        if (j < ns) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + j * (int)STEP * TT_LINE), 16, (int)goff, 0, 0, 0);
+            rx += b;
+            const bool wrap = rx >= R.bw;
+            rx = wrap ? rx - R.bw : rx;
+            goff += wrap ? inc_wrap : inc;
+        }
+    }
+}
+
 template <int NSEG>
 __device__ __forceinline__ void stage_commit_n(const Region& R, unsigned char* s_lines, int wid, int lane, int ns, const u32x4 (&v)[NSEG]) {
     unsigned char* dst = s_lines + (R.base + (unsigned)wid * 8u) * TT_LINE + (unsigned)lane * 16u;
+#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 2)
+    unsigned keep = 0;
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) if (j < ns) keep ^= v[j][0] ^ v[j][1] ^ v[j][2] ^ v[j][3];
+    if (keep == 0x12345678u && ns > 100) *reinterpret_cast<unsigned*>(dst) = keep;       // never happens: keeps the loads alive
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < NSEG; ++j)
         if (j < ns) *reinterpret_cast<u32x4*>(dst + j * 32 * TT_LINE) = v[j];
@@ -341,6 +387,13 @@ __device__ __forceinline__ unsigned make_regions(unsigned lo0, unsigned lo1, uns
     };
     const unsigned l0 = lines_of(R[0], TT_SEGS_A), l1 = lines_of(R[1], TT_SEGS_B), l2 = lines_of(R[2], TT_SEGS_A);
     unsigned mask;
+#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 1)
+    if (l0 <= cap && l1 <= cap && l2 <= cap) {
+        R[0].staged = R[1].staged = R[2].staged = true;
+        R[0].base = 0; R[1].base = (l0 + l1 <= cap) ? l0 : cap - l1; R[2].base = (l0 + l1 + l2 <= cap) ? l0 + l1 : cap - l2;
+        return 7u;
+    }
+#endif
     if (l0 + l1 + l2 <= cap) mask = 7u;
     else {
         const unsigned s01 = l0 + l1, s02 = l0 + l2, s12 = l1 + l2;
@@ -518,9 +571,24 @@ triplane_sample_tile_kernel(const TileArgs p) {
 // `s_barrier` per iteration hands everything over.  Same arithmetic, same tap table, same blend code as above: bit-equal results.
 // (First attempt, measured: stager waves doing T + F in sequence beside four blenders = 7.0k cycles per chunk for the stager against
 // 5.3k for the blender, 80.5 us — the same as the 4-wave kernel; the split below takes the fetch off the tap waves' critical path.)
-constexpr int PC_CAP = 504;                   // lines per buffer: 2 x (504 x 128 + 16 KB tap table) + 512 B = 162 304 B of the 160 KB
+// IDE3D_PC_EXP (timing experiments only, WRONG RESULTS; `make EXTRA=-DIDE3D_PC_EXP=n`, listed by ide3d_build_flags() with a '!'):
+//   1: every in-plane region counts as staged whatever the capacity (bases clamped into the buffer: regions overlap)
+//   2: the F waves skip their LDS writes          4: the blend reads lines whose bank halves alternate by slot (no bank conflicts)
+//   8: no output stores
+#ifndef IDE3D_PC_EXP
+#define IDE3D_PC_EXP 0
+#endif
+#ifndef IDE3D_PC_RWAVE
+#define IDE3D_PC_RWAVE 0                      // 1: wave 7 is a dedicated region builder R (F = waves 4-6) — measured 1-2 us SLOWER than 0 (T wave 0 builds the table beside its taps): R alone needs a whole iteration for the table chain and is last at the barrier instead
+#endif
+#ifndef IDE3D_PC_DMA
+#define IDE3D_PC_DMA 1                        // 1: the F waves fill the line buffers by LDS-DMA (stage_dma) instead of loads + ds_write
+#endif
 #ifndef IDE3D_PC_PRIO_T
 #define IDE3D_PC_PRIO_T 0                     // s_setprio per role (experiments)
+#endif
+#ifndef IDE3D_PC_PRIO_T0
+#define IDE3D_PC_PRIO_T0 0
 #endif
 #ifndef IDE3D_PC_PRIO_F
 #define IDE3D_PC_PRIO_F 0
@@ -539,6 +607,12 @@ __device__ unsigned long long g_pc_wg[1024][4];          // per workgroup (B wav
 #else
 #define IDE3D_PCT(role, k)
 #endif
+
+// = axis_tap().v: the virtual index of the low tap of one axis (the index half of the tap arithmetic)
+__device__ __forceinline__ unsigned axis_index(float c, int size) {
+    const float fu = floorf(unnormalize(c, size));
+    return (unsigned)(min(max((int)fminf(fmaxf(fu, -2.0f), (float)size + 1.0f), -1), size - 1) + 1);
+}
 
 template <int NB, int FR>      // NB: blender waves (4 or 8); FR: fetch rounds (1 = all three planes in flight at once, 2 = planes 0 + 1, then 2)
 __global__ void __launch_bounds__(64 * (8 + NB), (8 + NB) / 4)
@@ -578,6 +652,7 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
     if (wid < 4) {
         // ---------------------------------------------------------------- T: taps, bounding boxes, region + tap tables ----
         if (IDE3D_PC_PRIO_T) __builtin_amdgcn_s_setprio(IDE3D_PC_PRIO_T);
+        if (IDE3D_PC_PRIO_T0 && ridx == 0) __builtin_amdgcn_s_setprio(IDE3D_PC_PRIO_T0);          // the wave that builds the region table
         // phase-A sample of this lane: (ray rl of the tile, depth ds of the chunk); t_id = index among the 256 samples of a chunk
         const unsigned t_id = (unsigned)ridx * 64u + (unsigned)lane;
         const unsigned rl = t_id >> 2, ds = t_id & 3u;
@@ -590,10 +665,6 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
         // lane).  No exchange between the T waves: an LDS round trip takes hundreds of cycles while eight blending waves keep the LDS
         // queue full, and the first version (boxes posted to LDS, arrival counter, poll) spent 3 - 4k cycles per chunk there.  The
         // table is scalar work (the scalar unit is one per CU and 16 waves share it); F reads it one iteration later, T two later.
-        auto axis_index = [](float c, int size) {          // = axis_tap().v
-            const float fu = floorf(unnormalize(c, size));
-            return (unsigned)(min(max((int)fminf(fmaxf(fu, -2.0f), (float)size + 1.0f), -1), size - 1) + 1);
-        };
         auto build_regions = [&](const SampleTaps& t, const float (&oc)[3][3], u32x4* table) {
             unsigned lo0 = t.ax[0], lo1 = t.ax[1], hi0 = t.ax[0], hi1 = t.ax[1];
 #pragma unroll
@@ -614,7 +685,7 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
             return p.coords + (size_t)((img * (unsigned)p.rays_per_image + ray2) * (unsigned)p.steps + min(step + ds2, last_step)) * 3;
         };
         float oc[3][3] = {};
-        if (ridx == 0) {
+        if (!IDE3D_PC_RWAVE && ridx == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) { const float* q = other_coord_ptr(k + 1, step_begin); oc[k][0] = q[0]; oc[k][1] = q[1]; oc[k][2] = q[2]; }
         }
@@ -645,17 +716,53 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 {
                     const float* np_ = coord_ptr(step_begin + (unsigned)(it + 3) * TT_DS);
                     cx = np_[0]; cy = np_[1]; cz = np_[2];
-                    if (ridx == 0) {
+                    if (!IDE3D_PC_RWAVE && ridx == 0) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { const float* q = other_coord_ptr(k + 1, step_begin + (unsigned)(it + 3) * TT_DS); oc[k][0] = q[0]; oc[k][1] = q[1]; oc[k][2] = q[2]; }
                     }
                 }
                 IDE3D_PCT(0, 2)
-                if (ridx == 0) build_regions(t_hold, oc_now, s_reg[(unsigned)it & 1u]);
+                if (!IDE3D_PC_RWAVE && ridx == 0) build_regions(t_hold, oc_now, s_reg[(unsigned)it & 1u]);
             }
             IDE3D_PCT(0, 3)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             IDE3D_PCT(0, 4)
+        }
+    } else if (IDE3D_PC_RWAVE && wid == 7) {
+        // ---------------------------------------------------------------- R: region table (round 5) ----------------------------
+        // Wave 7 builds the region table of chunk it + 2 and does nothing else: the footprint origins of all 256 samples (4 per lane,
+        // from coordinates it loads itself one iteration ahead), the wave-wide reduction, the scalar table code — 2.5k cycles per chunk
+        // that used to sit on T wave 0 BEHIND its own taps and tap-table entries, which made that wave the last at the barrier in most
+        // iterations (gpurun_out -> profiles/round5/gather_experiments.txt).  The fill needs three waves, not four, since it is LDS-DMA.
+        const unsigned last_step = (unsigned)p.steps - 1u;
+        auto sample_ptr = [&](int k, unsigned step) {          // sample lane + 64 k of a chunk = (tile ray, depth)
+            const unsigned t2 = (unsigned)lane + 64u * (unsigned)k, rl2 = t2 >> 2, ds2 = t2 & 3u;
+            const unsigned ray2 = ray00 + (rl2 >> 3) * (unsigned)p.rays_w + (rl2 & 7u);
+            return p.coords + (size_t)((img * (unsigned)p.rays_per_image + ray2) * (unsigned)p.steps + min(step + ds2, last_step)) * 3;
+        };
+        float c[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float* q = sample_ptr(k, step_begin); c[k][0] = q[0]; c[k][1] = q[1]; c[k][2] = q[2]; }
+        for (int it = -2; it < nch; ++it) {
+            if (it + 2 < nch) {
+                float cn[4][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cn[k][0] = c[k][0]; cn[k][1] = c[k][1]; cn[k][2] = c[k][2]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float* q = sample_ptr(k, step_begin + (unsigned)(it + 3) * TT_DS); c[k][0] = q[0]; c[k][1] = q[1]; c[k][2] = q[2]; }
+                unsigned lo0 = 0xffffffffu, lo1 = 0xffffffffu, hi0 = 0u, hi1 = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned a0 = axis_index(cn[k][0], W) | (axis_index(cn[k][1], H) << 16);
+                    const unsigned a1 = axis_index(cn[k][1], W) | (axis_index(cn[k][2], H) << 16);
+                    lo0 = pk_min(lo0, a0); hi0 = pk_max(hi0, a0); lo1 = pk_min(lo1, a1); hi1 = pk_max(hi1, a1);
+                }
+                Region R[3];
+                wave_reduce_pk4(lo0, lo1, hi0, hi1);
+                const unsigned mask = make_regions(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, R);
+                store_regions(s_reg[(unsigned)it & 1u], R, mask, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     } else if (wid < 8) {
         // ---------------------------------------------------------------- F: region loads + LDS fill ------------------------
@@ -671,7 +778,19 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 // (Tried: the F waves touching one dword per line of the NOT staged planes, to pull them into L1 / L2 ahead of the blending
                 // waves' buffer loads — 64 separate lines per load instruction made F the slowest role: 73.5 vs 70.3 us.)
                 int n0 = 0, n1 = 0, n2 = 0;
-                if (FR == 1) {
+                if (IDE3D_PC_DMA && IDE3D_PC_RWAVE) {          // three fetching waves (4-6)
+                    if (R[0].staged) stage_dma<(TT_SEGS_A * 4 + 2) / 3, 3>(p, rsrc, R[0], 0, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    if (R[1].staged) stage_dma<(TT_SEGS_B * 4 + 2) / 3, 3>(p, rsrc, R[1], 1, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    if (R[2].staged) stage_dma<(TT_SEGS_A * 4 + 2) / 3, 3>(p, rsrc, R[2], 2, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    IDE3D_PCT(1, 1)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (IDE3D_PC_DMA) {
+                    if (R[0].staged) stage_dma<TT_SEGS_A>(p, rsrc, R[0], 0, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    if (R[1].staged) stage_dma<TT_SEGS_B>(p, rsrc, R[1], 1, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    if (R[2].staged) stage_dma<TT_SEGS_A>(p, rsrc, R[2], 2, img_bytes, ridx, slot, ch_bytes, s_lines);
+                    IDE3D_PCT(1, 1)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (FR == 1) {
                     u32x4 sva[TT_SEGS_A], svb[TT_SEGS_B], svc[TT_SEGS_A];
                     if (R[0].staged) n0 = stage_issue_buf(p, rsrc, R[0], 0, img_bytes, ridx, slot, ch_bytes, sva);
                     if (R[1].staged) n1 = stage_issue_buf(p, rsrc, R[1], 1, img_bytes, ridx, slot, ch_bytes, svb);
@@ -803,6 +922,15 @@ const char* triplane_tile_build_flags() {
     return ""
 #ifdef IDE3D_TT_TRACE
         "IDE3D_TT_TRACE "
+#endif
+#if IDE3D_PC_EXP
+        "!IDE3D_PC_EXP=" IDE3D_STR(IDE3D_PC_EXP) " "
+#endif
+#if !IDE3D_PC_DMA
+        "IDE3D_PC_DMA=0 "
+#endif
+#if !IDE3D_PC_RWAVE
+        "IDE3D_PC_RWAVE=0 "
 #endif
         ;
 }
