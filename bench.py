@@ -268,7 +268,7 @@ def _finite(o):
     return o
 
 
-OPTIONAL_KEYS = ('roofline_worst', 'dropin_eager_b1', 'parity_live', 'gather_overlap', 'frames_per_s_by_rank', 'timing', 'by_conv_arithmetic', 'parity')
+OPTIONAL_KEYS = ('roofline_worst', 'dropin_eager_b1', 'parity_live', 'gather_overlap', 'frames_per_s_by_rank', 'timing', 'by_conv_arithmetic', 'parity', 'roofline_step')
 
 
 def compact_line(out, limit=None):
@@ -290,10 +290,13 @@ def compact_line(out, limit=None):
 
 
 def dropin_eager_b1(G, device, palette, images=24, warm=4):
-    """What a drop-in caller of the reference's gen_images.py:88-114 gets: one seed at a time (batch 1), eager launches (no hipGraph),
-    the library-default arithmetic, `G.mapping` -> `G.synthesis(return_seg=True)` -> uint8 RGB | coloured seg frame, host latents per seed.
+    """What a drop-in caller of the reference's gen_images.py:88-114 gets: one seed at a time (batch 1), the loop body UNCHANGED — host
+    latents per seed, `G.mapping` -> `G.synthesis(return_seg=True)` -> uint8 RGB | coloured seg frame — in the library-default arithmetic.
+    Since round 5 `G.synthesis` itself captures a repeated call signature into a hipGraph and replays it (training/graph_cache.py):
+    `frames_per_s` is that loop as it runs; `eager_launches_frames_per_s` the same loop with the capture switched off (rounds 1-4).
     Timed over `images` seeds between two synchronisations."""
     from training import triplane
+    from training import graph_cache
     from training import distributed_render as dr
     cond = triplane.conditioning_label(device)
     cam = triplane.camera_label(0.0, device=device)
@@ -305,18 +308,26 @@ def dropin_eager_b1(G, device, palette, images=24, warm=4):
             img, seg = G.synthesis(ws, c=cam, noise_mode='const', return_seg=True)
             return dr.frames_u8(img, seg, palette)
 
-    for s in range(warm):
-        one(10_000 + s)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(images):
-        one(s)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed():
+        for s in range(warm):
+            one(10_000 + s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(images):
+            one(s)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    before = dict(graph_cache.STATS)
+    dt = timed()
+    stats = {k: graph_cache.STATS[k] - before.get(k, 0) for k in ('eager', 'capture', 'replay')}
     rec = {'frames_per_s': round(images / dt, 1), 'ms_per_image': round(dt / images * 1e3, 3), 'images': images,
-           'what': 'gen_images.py loop shape: batch 1, eager launches, library-default arithmetic'}
-    # the same loop with the two calls wrapped in a batch-1 hipGraph (`triplane.GraphedRenderer(G, 1, device)`: the one-line change a caller
-    # of gen_images.py can make): the eager loop is bound by its ~75 host-side launches per image, the replay by the GPU
+           'what': 'gen_images.py:88-114 loop shape, loop body unchanged: batch 1, library-default arithmetic; G.synthesis replays its own captured hipGraph',
+           'synthesis_calls': stats}
+    with graph_cache.disabled():
+        dt = timed()
+    rec['eager_launches_frames_per_s'] = round(images / dt, 1)
+    # the same loop with mapping AND synthesis inside one batch-1 hipGraph and pinned latents (`triplane.GraphedRenderer(G, 1, device)`)
     run = triplane.GraphedRenderer(G, 1, device, static_labels=True)
 
     def one_graphed(seed):
@@ -442,7 +453,10 @@ def main():
     # N > 1: the uint8 frames of step k travel to rank 0 (RCCL gather, 7 concurrent peer -> root xGMI copies) WHILE step k + 1 renders:
     # double-buffered send / receive tensors, `dist.gather(async_op=True)` on the communication stream (dr.OverlappedFrameGather).
     # `--blocking-gather` restores the synchronous gather on the compute stream (measured next to it as `ms_per_step_blocking_gather`).
-    og = dr.OverlappedFrameGather([BATCH, res, 2 * res, 3], device, rank, world) if dist else None
+    # `checksums`: every buffer sent / received in the timed blocks gets a position-weighted 64-bit checksum (sums of received buffers on a side
+    # stream); after the timed region rank 0 compares what arrived from every rank in EVERY timed step with what that rank says it sent
+    total_subs = max(1, args.blocks) * args.steps
+    og = dr.OverlappedFrameGather([BATCH, res, 2 * res, 3], device, rank, world, checksums=total_subs + 8) if dist else None
 
     def latents(i, r=None):
         seeds = [(i * world + (rank if r is None else r)) * BATCH + j for j in range(BATCH)]
@@ -477,6 +491,7 @@ def main():
         step(i, blocking=args.blocking_gather)
     block_s, rank_s = [], []
     done = args.warmup
+    first_timed_sub = og.submitted if (og is not None and not args.blocking_gather) else None
     for _b in range(max(1, args.blocks)):
         barrier()
         t0 = time.perf_counter()
@@ -494,6 +509,14 @@ def main():
 
     # N > 1 extras: per-rank frame rates (own clock, median block) and the cost of the RCCL gather alone
     per_rank, gather_ms, blocking_ms, gather_check = None, None, None, None
+    sums_bad = None
+    if dist and first_timed_sub is not None and og.submitted - first_timed_sub == total_subs:
+        barrier()
+        sent = og.sent_checksums(first_timed_sub, total_subs).contiguous()
+        every = [torch.zeros_like(sent) for _ in range(world)]
+        dist.all_gather(every, sent)
+        if rank == 0:
+            sums_bad = int((og.received_checksums(first_timed_sub, total_subs) != torch.stack(every, dim=1)).sum())
     if dist:
         mine = torch.tensor([BATCH * args.steps / sorted(rank_s)[len(rank_s) // 2]], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -537,8 +560,10 @@ def main():
                     with torch.no_grad():
                         want = dr.frames_u8(img, seg, palette)
                     bad += int((subs[k][r] != want).any())
-            gather_check = {'ok': bad == 0, 'steps': 3, 'ranks': world, 'mismatching_buffers': bad,
-                            'what': 'frames received through the double-buffered async gather == frames rank 0 renders for the same (step, rank) inputs'}
+            gather_check = {'ok': bad == 0 and not sums_bad, 'steps': 3, 'ranks': world, 'mismatching_buffers': bad,
+                            'what': 'frames received through the double-buffered async gather == frames rank 0 renders for the same (step, rank) inputs; '
+                                    'and, for EVERY timed step, the 64-bit checksum of what arrived from each rank == the checksum that rank formed of what it sent',
+                            'checksummed_steps': None if sums_bad is None else total_subs, 'checksum_mismatches': sums_bad}
         done += 3
 
     if rank == 0:
@@ -636,6 +661,21 @@ def main():
                 out['roofline_worst'] = [{'kernel': str(r.get('name', r.get('kernel', '?')))[:60], 'bound': r.get('bound'), 'frac': r3(r['frac'], 3),
                                           'us': r3(r.get('us', r.get('avg_us')), 1)} for r in rows[:5]]
                 out['roofline_rows'] = len(rows)
+                # the kernel that governs the frame rate (not only the isolated gather the metric names): the shared-weight 3x3 stride-1
+                # convolutions of the 64^2 .. 256^2 layers — four launches of modconv_split_kernel<0,1,16,...> per step in the default arithmetic
+                dom = [r for r in rows if r.get('kernel') == 'modconv_split_kernel' and f'[{arith}]' in r.get('name', '')
+                       and any(t in r['name'] for t in ('3x3 512->512 @64', '3x3 256->256 @128', '3x3 128->128 @256'))]
+                if dom and arith in ('bf16x6', 'f16x3', 'bf16x3'):
+                    per_step = {'3x3 512->512 @64': 1, '3x3 256->256 @128': 1, '3x3 128->128 @256': 2}      # vb64.conv1, vb128.conv1, vb256.conv1 + b256.conv1
+                    us = sum(r['us'] * n for r in dom for t, n in per_step.items() if t in r['name'])
+                    fl = sum(r['algorithmic_flops'] * n for r in dom for t, n in per_step.items() if t in r['name'])
+                    peak = dom[0]['peak']
+                    pm = kernel_rooflines._pmc_notes()
+                    busy = next((v for k, v in pm.items() if k.startswith('modconv_split_kernel<0, 1, 16')), None)
+                    out['roofline_step'] = {'kernel': 'modconv_split_kernel<0,1,16,3,2,8,0> (3x3 stride-1, 64^2..256^2 layers)', 'bound': f'mfma:{arith}', 'launches_per_step': 4,
+                                            'us_per_step': r3(us, 1), 'share_of_step': r3(us / (med / args.steps * 1e6), 3), 'achieved': r3(fl / us / 1e6, 1), 'peak': r3(peak, 1),
+                                            'unit': 'TFLOP/s', 'frac': r3(fl / us / 1e6 / peak, 3),
+                                            'mfma_busy_frac': None if busy is None else busy['mfma_busy_frac'], 'mfma_busy_measured_in_this_run': False}
             except Exception as e:
                 out['roofline_worst'] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not cpu and world == 1 and not args.no_cpu_baseline:

@@ -59,32 +59,80 @@ class OverlappedFrameGather:
     streams again.  On `dst`, `received(i)` is the list of per-rank buffers of submission i (valid after `drain()` or after the
     matching `wait(i)`); a buffer is reused `depth` submissions later.  Nothing like it upstream: the reference renders on one GPU."""
 
-    def __init__(self, shape, device, rank, world, dst=0, depth=2, dtype=torch.uint8):
+    def __init__(self, shape, device, rank, world, dst=0, depth=2, dtype=torch.uint8, checksums=0):
+        """`checksums=K` (> 0): a position-weighted 64-bit checksum of every buffer sent (all ranks) and received (on `dst`) is kept for the
+        last K submissions — `sent_checksums()` / `received_checksums()` — so that a whole run can be verified, not a sample of it
+        (`bench.py gather_check`).  The sums of a received buffer are formed on a side stream once its gather has completed; the compute
+        stream only waits for them before it reuses that buffer `depth` submissions later."""
         import torch.distributed as dist
         self._dist, self.rank, self.world, self.dst, self.depth = dist, rank, world, dst, depth
         self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(world)] if rank == dst else None for _ in range(depth)]
         self.work = [None] * depth
         self.submitted = 0
+        self.cap = int(checksums)
+        if self.cap:
+            nbytes = self.send[0].numel() * self.send[0].element_size()
+            assert nbytes % 8 == 0, 'checksums view the buffers as 64-bit words'
+            self._mult = torch.arange(1, nbytes // 8 + 1, dtype=torch.int64, device=device) * 2 + 1          # odd multipliers: position matters
+            self._sent = torch.zeros([self.cap], dtype=torch.int64, device=device)
+            self._rcvd = torch.zeros([self.cap, world], dtype=torch.int64, device=device) if rank == dst else None
+            self._pending = [None] * depth          # submission number whose received buffers have not been summed yet
+            cuda = torch.device(device).type == 'cuda'
+            self._check_stream = torch.cuda.Stream(device=device) if cuda else None
+            self._checked = [None] * depth          # event: sums of the buffers in slot b are done (the buffer may be overwritten)
+
+    def _sum64(self, buf):
+        return (buf.reshape(-1).view(torch.int64) * self._mult).sum()
+
+    def _wait_slot(self, b):
+        """Order the current stream behind the gather of slot b (if one is in flight).  With checksums: the sums of what arrived are formed
+        on the side stream, which waits for the COLLECTIVE only — not for whatever the compute stream has queued (the render of the current
+        step) — so they run beside the rendering."""
+        w = self.work[b]
+        if w is None:
+            return
+        self.work[b] = None
+        i = self._pending[b] if self.cap else None
+        if i is not None:
+            self._pending[b] = None
+            if self._rcvd is not None:
+                if self._check_stream is not None:
+                    with torch.cuda.stream(self._check_stream):
+                        w.wait()
+                        for r in range(self.world):
+                            self._rcvd[i % self.cap, r] = self._sum64(self.recv[b][r])
+                        ev = torch.cuda.Event(); ev.record(self._check_stream)
+                    self._checked[b] = ev
+                    w.wait()
+                    return
+                w.wait()
+                for r in range(self.world):
+                    self._rcvd[i % self.cap, r] = self._sum64(self.recv[b][r])
+                return
+        w.wait()
 
     def wait(self, i):
         """Wait (stream-ordered on the GPU) for submission number i, if it is still in flight."""
         b = i % self.depth
-        if self.work[b] is not None and self.submitted - i <= self.depth:
-            self.work[b].wait()
-            self.work[b] = None
+        if self.submitted - i <= self.depth:
+            self._wait_slot(b)
 
     def slot(self):
         """The send buffer of the next submission; its previous use has completed when this returns."""
         b = self.submitted % self.depth
-        if self.work[b] is not None:
-            self.work[b].wait()
-            self.work[b] = None
+        self._wait_slot(b)
+        if self.cap and self._checked[b] is not None:
+            torch.cuda.current_stream(self.send[0].device).wait_event(self._checked[b])       # the receive buffers of this slot are about to be overwritten
+            self._checked[b] = None
         return self.send[b]
 
     def submit(self):
         """Start the gather of the buffer `slot()` returned; returns the submission number."""
         b = self.submitted % self.depth
+        if self.cap:
+            self._sent[self.submitted % self.cap] = self._sum64(self.send[b])
+            self._pending[b] = self.submitted
         self.work[b] = self._dist.gather(self.send[b], self.recv[b], dst=self.dst, async_op=True)
         self.submitted += 1
         return self.submitted - 1
@@ -94,9 +142,19 @@ class OverlappedFrameGather:
 
     def drain(self):
         for b in range(self.depth):
-            if self.work[b] is not None:
-                self.work[b].wait()
-                self.work[b] = None
+            self._wait_slot(b)
+        if self.cap and self._check_stream is not None:
+            torch.cuda.current_stream(self.send[0].device).wait_stream(self._check_stream)
+
+    def sent_checksums(self, first, count):
+        """int64 [count]: checksums of this rank's submissions first .. first + count - 1 (the last `checksums` submissions are kept)."""
+        assert self.cap and count <= self.cap and first + count <= self.submitted and first >= self.submitted - self.cap
+        return self._sent[torch.arange(first, first + count, device=self._sent.device) % self.cap]
+
+    def received_checksums(self, first, count):
+        """int64 [count, world] on `dst` (after `drain()`): checksums of what arrived from every rank in those submissions."""
+        assert self.cap and self._rcvd is not None and count <= self.cap and first + count <= self.submitted and first >= self.submitted - self.cap
+        return self._rcvd[torch.arange(first, first + count, device=self._rcvd.device) % self.cap]
 
 
 def shard_items(num_seeds: int, num_poses: int, rank: int, world: int) -> List[Tuple[int, int]]:

@@ -31,6 +31,7 @@ def test_launch_ranks_function_two_gloo_ranks():
     assert 'DRY RUN' in rec['metric']
     # the double-buffered asynchronous gather: contents and order checked by rank 0 against its own render of every rank's inputs
     assert rec['gather_check']['ok'] is True and rec['gather_check']['steps'] == 3 and rec['gather_check']['ranks'] == 2
+    assert rec['gather_check']['checksum_mismatches'] == 0 and rec['gather_check']['checksummed_steps'] == rec['steps'] * rec['timing']['blocks']      # every timed step
     ov = rec['gather_overlap']
     assert ov['ms_per_step_overlapped'] > 0 and ov['ms_per_step_blocking_gather'] > 0 and ov['gather_ms_alone'] > 0
 

@@ -119,3 +119,45 @@ def test_overlapped_frame_gather_order_and_contents(tmp_path):
     out = str(tmp_path / 'seen.npy')
     mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert np.load(out).tolist() == [[s * 10, s * 10 + 1] for s in range(5)]
+
+
+def _checksum_worker(rank, world, port, out_path):
+    for p in (os.path.join(ROOT, 'ide-3d_amd'), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from training import distributed_render as dr
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    og = dr.OverlappedFrameGather([2, 4, 8, 3], torch.device('cpu'), rank, world, depth=2, checksums=6)
+    g = torch.Generator().manual_seed(100 + rank)
+    for step in range(9):                          # more submissions than the checksum ring keeps: only the last 6 can be asked for
+        og.slot().copy_(torch.randint(0, 256, (2, 4, 8, 3), generator=g, dtype=torch.uint8))
+        og.submit()
+    og.drain()
+    sent = og.sent_checksums(3, 6).contiguous()
+    every = [torch.zeros_like(sent) for _ in range(world)]
+    dist.all_gather(every, sent)
+    if rank == 0:
+        rc = og.received_checksums(3, 6)
+        buf = og.received(8)[1].clone()
+        a = int(og._sum64(buf))
+        buf.view(-1)[5] ^= 1                       # one bit in one byte
+        b = int(og._sum64(buf))
+        swapped = og.received(8)[1].clone().view(-1)
+        swapped[:8], swapped[8:16] = swapped[8:16].clone(), swapped[:8].clone()      # two 64-bit words exchanged: a plain sum would not see it
+        c = int(og._sum64(swapped.view(2, 4, 8, 3)))
+        np.save(out_path, np.array([int((rc != torch.stack(every, dim=1)).sum()), int(a == b), int(a == c and not torch.equal(swapped[:8], swapped[8:16])),
+                                    int(len(set(sent.tolist())) == 6)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_frame_gather_checksums_cover_every_submission(tmp_path):
+    """`checksums=K`: what arrived from every rank in each of the last K submissions has the checksum the sender formed; the checksum sees a
+    flipped bit and two exchanged words (bench.py `gather_check.checksummed_steps`)."""
+    out = str(tmp_path / 'sums.npy')
+    mp.spawn(_checksum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mismatches, blind_to_bit, blind_to_swap, distinct = np.load(out).tolist()
+    assert mismatches == 0 and blind_to_bit == 0 and blind_to_swap == 0 and distinct == 1
