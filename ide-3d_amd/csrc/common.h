@@ -25,6 +25,34 @@ void set_error(const char* fmt, ...);
 const char* modconv_build_flags();
 const char* triplane_tile_build_flags();
 const char* raymarch_build_flags();
+
+// Exclusive residency is a property of the built kernel ON the device it runs on: an LDS-fed bf16 / fp16 matrix loop
+// must be the only workgroup on its CU.  It follows from register claims and workgroup sizes; a toolchain that splits the register file
+// differently, or a partitioned / CU-masked device, could silently break it.  Every launch of such a kernel goes through
+// IDE3D_EXCL_LAUNCH, which asks the runtime ONCE per (kernel instantiation, device) how many workgroups fit a CU; anything but one is
+// recorded (ide3d_exclusive_violations(), checked by hip_plugin and the GPU tests) and the launch fails loudly with IDE3D_ELAUNCH.
+void note_exclusive_violation(const char* kernel, int blocks_per_cu);
+void refuse_launch(const char* kernel);          // this thread's next IDE3D_CHECK_LAUNCH fails
+bool take_refused();
+int exclusive_violations();
+template <typename K>
+inline bool exclusive_on_this_device(K kernel, int threads, size_t dyn_lds, const char* name) {
+    static int occ[16] = {};                       // per instantiation (this is a template) and device: 0 = not asked yet
+#ifdef IDE3D_SP_SHARED_SIMD
+    return true;                                   // A/B experiment build without the register claims
+#endif
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+    if (occ[dev] == 0) {
+        int n = 0;
+        occ[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) == hipSuccess && n > 0) ? n : -1;
+        if (occ[dev] > 1) note_exclusive_violation(name, occ[dev]);
+    }
+    if (occ[dev] > 1) refuse_launch(name);
+    return occ[dev] <= 1;
+}
+#define IDE3D_EXCL_LAUNCH(KERNEL, GRID, THREADS, DYN_LDS, ST, ...) \
+    do { if (ide3d::exclusive_on_this_device(KERNEL, (THREADS), (DYN_LDS), #KERNEL)) hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), DYN_LDS, ST, __VA_ARGS__); } while (0)
 #define IDE3D_STR_(x) #x
 #define IDE3D_STR(x) IDE3D_STR_(x)
 
@@ -34,7 +62,8 @@ const char* raymarch_build_flags();
 #define IDE3D_CHECK_LAUNCH(what)                                     \
     do { hipError_t e_ = hipGetLastError();                          \
          if (e_ != hipSuccess) { ide3d::set_error("%s: %s", what, hipGetErrorString(e_)); \
-                                 return IDE3D_ELAUNCH; } } while (0)
+                                 return IDE3D_ELAUNCH; }                \
+         if (ide3d::take_refused()) return IDE3D_ELAUNCH; } while (0)
 
 // ---- element type <-> fp32 math type ----------------------------------------------------------
 

@@ -1,6 +1,7 @@
 // core.hip — error reporting and library identity for libide3d_hip.so.
 #include "common.h"
 #include <string.h>
+#include <stdio.h>
 
 namespace ide3d {
 
@@ -13,8 +14,26 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_excl_violations = 0;
+static char g_excl_text[384] = "";
+void note_exclusive_violation(const char* kernel, int blocks_per_cu) {
+    ++g_excl_violations;
+    snprintf(g_excl_text, sizeof(g_excl_text), "%d workgroups of %.200s fit one CU of this device: exclusive residency (DESIGN.md 4.2) does not hold", blocks_per_cu, kernel);
+    fprintf(stderr, "[libide3d_hip] %s; the launch is refused (select IDE3D_CONV_ARITH=fp32)\n", g_excl_text);
+}
+int exclusive_violations() { return g_excl_violations; }
+static thread_local bool g_refused = false;
+void refuse_launch(const char* kernel) {
+    g_refused = true;
+    set_error("%.200s: more than one workgroup fits a CU of this device, exclusive residency (DESIGN.md 4.2) does not hold; launch refused "
+              "(IDE3D_CONV_ARITH=fp32 selects the arithmetic that needs none)", kernel);
+}
+bool take_refused() { const bool r = g_refused; g_refused = false; return r; }
+
 }  // namespace ide3d
 
+extern "C" int ide3d_exclusive_violations(void) { return ide3d::g_excl_violations; }
+extern "C" const char* ide3d_exclusive_violation_text(void) { return ide3d::g_excl_text; }
 extern "C" const char* ide3d_last_error(void) { return ide3d::g_err; }
 extern "C" int ide3d_abi_version(void) { return 6; }
 extern "C" const char* ide3d_build_arch(void) { return "gfx950"; }

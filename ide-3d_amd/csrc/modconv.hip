@@ -1994,27 +1994,27 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
         if constexpr (MODE == MODE_TCONV3A) {
             if constexpr (BIG == 2) {
                 if (form.teams) {
-                    hipLaunchKernelGGL((modconv_split_teams_kernel<MODE, BIG, 4, PARTS, 2, F16>), dim3(nblocks / 2), dim3(512), 0, st, p, wu, partial, g, ru);
+                    IDE3D_EXCL_LAUNCH((modconv_split_teams_kernel<MODE, BIG, 4, PARTS, 2, F16>), dim3(nblocks / 2), 512, 0, st, p, wu, partial, g, ru);
                     return;
                 }
             }
-            hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+            IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 4, PARTS, 2, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
         }
     }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
         static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr && !kSpExclusive;
-        if (form.waves == 8) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
-        else if (one_wbuf && MODE == MODE_CONV3) hipLaunchKernelGGL((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        if (form.waves == 8) IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), 512, 0, st, p, wu, partial, g, ru);
+        else if (one_wbuf && MODE == MODE_CONV3) IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
+        else IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
     }
     else if (pl.tile == 12) {
         if constexpr (MODE == MODE_CONV3 && BIG == 2)
-            hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 32, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
+            IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 32, PARTS, 2, 8, F16>), dim3(nblocks), 512, 0, st, p, wu, partial, g, ru);
     }
     else if constexpr (MODE == MODE_CONV3 || BIG == 2) {
-        if (form.waves == 8) hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), dim3(512), 0, st, p, wu, partial, g, ru);
-        else hipLaunchKernelGGL((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), dim3(256), 0, st, p, wu, partial, g, ru);
+        if (form.waves == 8) IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 8, F16>), dim3(nblocks), 512, 0, st, p, wu, partial, g, ru);
+        else IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 16, PARTS, 2, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
     }
 }
 
@@ -2107,11 +2107,11 @@ extern "C" int ide3d_modconv2d(const ide3d_modconv_params* pp, void* stream) {
         const int tiles = cdiv(p.h * p.w_, 32 * head_waves(mt));
         const int hw_h = p.h * p.w_, wgs_img = kNumCU / p.n, tiles32 = hw_h / 32;
         const bool resident = head_resident_applies(p);
-#define IDE3D_HEAD_RES(P, M, C) hipLaunchKernelGGL((head_resident_kernel<P, M, C>), dim3(p.n * wgs_img), dim3(512), 0, st_head, p, wu, wgs_img, tiles32)
+#define IDE3D_HEAD_RES(P, M, C) IDE3D_EXCL_LAUNCH((head_resident_kernel<P, M, C>), dim3(p.n * wgs_img), 512, 0, st_head, p, wu, wgs_img, tiles32)
 #define IDE3D_HEAD(P, M) do { \
             hipLaunchKernelGGL(head_pack_split_kernel<P>, dim3(stream_grid(items, 256)), dim3(256), 0, st_head, p.w, p.w_batch_stride, p.n, p.cout, p.cin, M * 32, cchunks, wu); \
             if (resident) { if (M == 6) IDE3D_HEAD_RES(P, 6, 8); else if (cchunks == 4) IDE3D_HEAD_RES(P, 1, 4); else IDE3D_HEAD_RES(P, 1, 8); } \
-            else hipLaunchKernelGGL((head_split_kernel<P, M>), dim3(p.n * tiles), dim3(64 * head_waves(M)), 0, st_head, p, wu, cchunks, tiles); } while (0)
+            else IDE3D_EXCL_LAUNCH((head_split_kernel<P, M>), dim3(p.n * tiles), 64 * head_waves(M), 0, st_head, p, wu, cchunks, tiles); } while (0)
         if (parts == 2) { if (mt == 1) IDE3D_HEAD(2, 1); else IDE3D_HEAD(2, 6); }
         else            { if (mt == 1) IDE3D_HEAD(3, 1); else IDE3D_HEAD(3, 6); }
 #undef IDE3D_HEAD

@@ -870,7 +870,8 @@ static int launch_render(const ide3d_render_params& p, hipStream_t st) {
     nblk = cdiv64(total_rays, rpb);
     auto kern = render_rays_kernel<C, HID, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, rpb);
+    if constexpr (SPLIT) IDE3D_EXCL_LAUNCH(kern, dim3((unsigned)nblk), 64 * NW, lds_bytes, st, p, rpb);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, rpb);
     IDE3D_CHECK_LAUNCH("render_rays");
     return IDE3D_OK;
 }
@@ -896,7 +897,8 @@ static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m,
         nblk = cdiv64(nsuper, spb);
         auto kern = density_kernel<C, HID, Src, SPLIT>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out_sigma, spb);
+        if constexpr (SPLIT) IDE3D_EXCL_LAUNCH(kern, dim3((unsigned)nblk), 64 * NW, lds_bytes, st, p, src, m, out_sigma, spb);
+        else hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out_sigma, spb);
         IDE3D_CHECK_LAUNCH("sample_voxel (densities)");
         return IDE3D_OK;
     }
@@ -909,7 +911,8 @@ static int launch_voxel(const ide3d_render_params& p, const Src& src, int64_t m,
     nblk = cdiv64(ntiles, tpb);
     auto kern = sample_voxel_kernel<C, HID, Src, SPLIT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out, tpb);
+    if constexpr (SPLIT) IDE3D_EXCL_LAUNCH(kern, dim3((unsigned)nblk), 64 * NW, lds_bytes, st, p, src, m, out, tpb);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, st, p, src, m, out, tpb);
     IDE3D_CHECK_LAUNCH("sample_voxel");
     return IDE3D_OK;
 }

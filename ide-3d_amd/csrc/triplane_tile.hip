@@ -929,8 +929,8 @@ const char* triplane_tile_build_flags() {
 #if !IDE3D_PC_DMA
         "IDE3D_PC_DMA=0 "
 #endif
-#if !IDE3D_PC_RWAVE
-        "IDE3D_PC_RWAVE=0 "
+#if IDE3D_PC_RWAVE
+        "IDE3D_PC_RWAVE=1 "
 #endif
         ;
 }

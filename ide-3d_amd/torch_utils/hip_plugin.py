@@ -280,7 +280,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = (
-    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_build_flags', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
+    'ide3d_last_error', 'ide3d_abi_version', 'ide3d_build_arch', 'ide3d_build_flags', 'ide3d_exclusive_violations', 'ide3d_exclusive_violation_text', 'ide3d_bias_act', 'ide3d_upfirdn2d', 'ide3d_upfirdn2d_ex',
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
@@ -288,6 +288,15 @@ EXPORTED_SYMBOLS = (
     'ide3d_style_demod_batch', 'ide3d_fold_heads_batch',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
 )
+
+
+def exclusive_violations():
+    """(count, text): kernels with an LDS-fed bf16 / fp16 matrix loop that would NOT be alone on their CU on this device (their launches are
+    refused with a RuntimeError); (0, '') everywhere the library is supported.  See ide3d_exclusive_violations (include/ide3d_hip.h)."""
+    lib = load()
+    lib.ide3d_exclusive_violations.restype = ctypes.c_int
+    lib.ide3d_exclusive_violation_text.restype = ctypes.c_char_p
+    return int(lib.ide3d_exclusive_violations()), lib.ide3d_exclusive_violation_text().decode('utf-8', 'replace')
 
 
 def _check(rc, what):

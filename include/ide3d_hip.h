@@ -42,6 +42,11 @@ const char* ide3d_build_arch(void);
  * IDE3D_HEAD_DBG / IDE3D_F16_BF16MFMA (wrong values by design) and IDE3D_SP_SHARED_SIMD (no exclusive residency) — is listed
  * with a leading '!'; the host side (`hip_plugin.load()`) refuses such a library unless IDE3D_ALLOW_EXPERIMENT_BUILD=1 is set. */
 const char* ide3d_build_flags(void);
+/* ABI 6.  Kernels that contain an LDS-fed bf16 / fp16 matrix loop keep other waves off their SIMDs (one workgroup per CU: DESIGN.md 4.2).  The
+ * library asks the HIP runtime, once per kernel and device, whether that holds where it runs (hipOccupancyMaxActiveBlocksPerMultiprocessor == 1);
+ * a kernel for which it does not is never launched (the call returns IDE3D_ELAUNCH) and counted here.  0 on every supported configuration. */
+int         ide3d_exclusive_violations(void);
+const char* ide3d_exclusive_violation_text(void);
 
 /* ---- bias_act ------------------------------------------------------------------------- */
 /*

@@ -644,3 +644,29 @@ def test_transposed_strip_plan_equals_full_grid(gpu_device, shape, name):
         e_full = float((y_strip[sl] - y_full[sl]).abs().max()) / scale
         assert e_ref < 4e-6 and e_full < (2e-5 if name == 'bf16x3' else 8e-6), f'{part}: vs float64 {e_ref:.2e}, vs the full-grid plan {e_full:.2e}'
     assert torch.equal(am_strip.amax(dim=1), y_strip.abs().amax(dim=(1, 2, 3))), 'y_amax must cover the strip'
+
+
+def test_every_matrix_loop_is_alone_on_its_cu_on_this_device(gpu_device):
+    """Exclusive residency is checked where the kernels RUN, not assumed from the source: every launch of a kernel with an
+    LDS-fed bf16 / fp16 matrix loop first asks the runtime how many of its workgroups fit one CU of this device
+    (hipOccupancyMaxActiveBlocksPerMultiprocessor, once per kernel and device) and is refused unless the answer is one.  A full-size batch-4
+    pass in every split arithmetic reaches all of them (3x3, transposed, two-team, low-resolution split-K forms, both head kernels, the
+    ray-marcher with bf16x6 MLPs): none may have been refused."""
+    from torch_utils import hip_plugin
+    from training import graph_cache, triplane
+    torch.manual_seed(0)
+    G = triplane.TriPlaneGenerator().eval().requires_grad_(False).to(gpu_device)
+    ws = torch.randn(4, G.num_ws, G.w_dim, device=gpu_device)
+    c = torch.cat([triplane.camera_label(y, device=gpu_device) for y in (-0.5, 0.0, 0.5, 0.25)])
+    keep = hip_plugin.conv_arithmetic()
+    try:
+        for arith in ('bf16x6', 'f16x3', 'bf16x3'):
+            hip_plugin.conv_arithmetic(arith)
+            with torch.no_grad(), graph_cache.disabled():
+                img, seg = G.synthesis(ws, c=c, noise_mode='const', return_seg=True)
+                img1, _ = G.synthesis(ws[:1], c=c[:1], noise_mode='const', return_seg=True)          # batch 1 plans other forms (more split-K)
+            assert torch.isfinite(img).all() and torch.isfinite(img1).all()
+    finally:
+        hip_plugin.conv_arithmetic(keep)
+    torch.cuda.synchronize()
+    assert hip_plugin.exclusive_violations() == (0, ''), hip_plugin.exclusive_violations()
