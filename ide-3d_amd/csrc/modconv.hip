@@ -2063,13 +2063,22 @@ extern "C" int64_t ide3d_modconv_workspace_bytes(int32_t n, int32_t cin, int32_t
     if (check_modconv(p) != IDE3D_OK) return -1;
     p.x = nullptr;                               // alignment of the real tensor is unknown here: size for the larger plan
     // sized for every arithmetic (the packed copy of the split-bf16 loops is the larger one) and for the flattened 1x1 plan
+    // ... and for both epilogue classes: the plan depends on the epilogue (the strip / one-round forms of the transposed layers need the plain
+    // one: demodulation only), so the sizing plans with the plain epilogue AND with the convolution layers' (noise, bias, activation) and takes
+    // the larger of each part — a launch can then never pick a tile / split-K / strip the workspace was not sized for.
     int64_t packed = 0, part = 0;
-    for (int arith : {1, 3, 6, 16}) {
-        ConvPlan pl; plan_conv(p, pl, arith);
-        ConvPlan pf; plan_conv(flatten_pointwise(p), pf, arith);
-        for (const ConvPlan* q : {&pl, &pf}) {
-            if (q->packed_floats + q->aux_floats > packed) packed = q->packed_floats + q->aux_floats;
-            if (q->partial_floats > part) part = q->partial_floats;
+    static const float dummy = 0.f;
+    for (int epi = 0; epi < 2; ++epi) {
+        ide3d_modconv_params q0 = p;
+        q0.act = 1; q0.gain = 1.f; q0.clamp = -1.f;
+        if (epi == 1) { q0.noise = &dummy; q0.bias = &dummy; q0.noise_strength = 1.f; q0.act = 3; q0.alpha = 0.2f; q0.gain = 1.41421356f; }      // never dereferenced: plan_conv only tests them
+        for (int arith : {1, 3, 6, 16}) {
+            ConvPlan pl; plan_conv(q0, pl, arith);
+            ConvPlan pf; plan_conv(flatten_pointwise(q0), pf, arith);
+            for (const ConvPlan* q : {&pl, &pf}) {
+                if (q->packed_floats + q->aux_floats > packed) packed = q->packed_floats + q->aux_floats;
+                if (q->partial_floats > part) part = q->partial_floats;
+            }
         }
     }
     int64_t bytes = (packed + part) * (int64_t)sizeof(float);

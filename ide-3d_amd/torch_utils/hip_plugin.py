@@ -1137,9 +1137,15 @@ class MappingPlugin:
             return bool(load().ide3d_mapping_supported())            # the kernel's grid barrier needs its 64 workgroups co-resident
 
     @staticmethod
-    def mapping(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff):
-        """z [n, z_dim], c [n, c_dim] | None, raw parameters of the embed / fc layers -> ws [n, num_ws, w_dim] (one launch)."""
+    def mapping(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff, trusted=False):
+        """z [n, z_dim], c [n, c_dim] | None, raw parameters of the embed / fc layers -> ws [n, num_ws, w_dim] (one launch).
+        `trusted`: the caller has passed these very parameter objects (and this batch size) through the checks before; only z / c are checked."""
         dev = z.device
+        if trusted:
+            _require(z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and (c is None or (c.device == dev and c.dtype == torch.float32 and c.is_contiguous()
+                                                                                                 and tuple(c.shape) == (z.shape[0], embed_w.shape[1]))),
+                     'mapping: z / c must be contiguous float32 tensors on one CUDA device, c [n, c_dim]')
+            return MappingPlugin._launch(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff)
         f32c = lambda t: t is None or (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous())
         _require(all(f32c(t) for t in (z, c, embed_w, embed_b, w_avg, *fc_ws, *fc_bs)), 'mapping: contiguous float32 tensors on one CUDA device required')
         n, z_dim = z.shape
@@ -1156,6 +1162,14 @@ class MappingPlugin:
         for w, b in zip(fc_ws, fc_bs):
             _require(w.ndim == 2 and w.shape[1] == k and (b is None or tuple(b.shape) == (w.shape[0],)), 'mapping: layer widths do not chain')
             k = w.shape[0]
+        return MappingPlugin._launch(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff)
+
+    @staticmethod
+    def _launch(z, c, embed_w, embed_b, embed_wgain, embed_bgain, fc_ws, fc_bs, lr_multiplier, alpha, act_gain, num_ws, w_avg, psi, cutoff):
+        dev = z.device
+        n, z_dim = z.shape
+        embed = 0 if embed_w is None else embed_w.shape[0]
+        k = fc_ws[-1].shape[0]
         lib = load()
         key = (dev.index, _ws_domain(dev))
         wsp = MappingPlugin._ws.get(key)

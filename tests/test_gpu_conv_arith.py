@@ -470,6 +470,8 @@ def _pk_victim_lib():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import __graft_entry__
         path = __graft_entry__.build_test_natives()
+    if not os.path.isfile(path):
+        pytest.skip('tests/native/pk_victim.hip could not be built here (hipcc output above)')
     lib = ctypes.CDLL(path)
     lib.pk_victim_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.pk_aggressor_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
