@@ -940,14 +940,14 @@ def test_style_batch_equals_per_layer(gpu_device):
 def test_mapping_batch_sizes_across_the_one_block_threshold_agree(gpu_device):
     """the fused mapping kernel sums a row's products in another order when a wave owns a whole row block (small batches) than
     when it does not, so `ws` is not bitwise identical across batch sizes — only to rounding.  Rows of one latent computed at batch 1, 4, 5
-    and 8 agree within a few ulp of the layer outputs' scale, and the batch-1 row is what the float64 definition gives."""
+    and 8 agree within a few ulp of the layer outputs' scale, and every one of them is what the layer-by-layer definition gives on the CPU."""
     from training import networks
     torch.manual_seed(5)
     M = networks.MappingNetwork(512, 25, 512, 18).eval()
     z = torch.randn(8, 512); c = torch.randn(8, 25)
     with torch.no_grad():
-        want = M.double()(z.double(), c.double())          # float64 definition on the CPU
-    Md = M.float().to(gpu_device)
+        want = M(z, c).double()                            # the layer-by-layer definition on the CPU (fp32)
+    Md = M.to(gpu_device)
     zs, cs = z.to(gpu_device), c.to(gpu_device)
     rows = {}
     with torch.no_grad():
@@ -955,5 +955,5 @@ def test_mapping_batch_sizes_across_the_one_block_threshold_agree(gpu_device):
             rows[n] = Md(zs[:n], cs[:n])[0].cpu()
     scale = float(want.abs().max())
     for n, r in rows.items():
-        assert float((r.double() - want[0]).abs().max()) <= 2e-5 * scale, f'batch {n} vs float64'
+        assert float((r.double() - want[0]).abs().max()) <= 2e-5 * scale, f'batch {n} vs the CPU definition'
         assert float((r - rows[1]).abs().max()) <= 4e-6 * scale, f'batch {n} vs batch 1: more than rounding'
