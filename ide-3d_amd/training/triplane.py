@@ -459,7 +459,7 @@ INTRINSICS = (4.2647, 0.0, 0.5, 0.0, 4.2647, 0.5, 0.0, 0.0, 1.0)     # gen_image
 def conditioning_label(device='cpu'):
     """Frontal 25-D label the mapping network is conditioned on (gen_images.py:87)."""
     pose = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 2.7, 0, 0, 0, 1]
-    return torch.tensor(pose + list(INTRINSICS), dtype=torch.float32, device=device).reshape(1, -1)
+    return vr.device_const(pose + list(INTRINSICS), torch.float32, device).reshape(1, -1).clone()
 
 
 def camera_label(yaw, pitch=math.pi * 0.5, radius=2.7, device='cpu'):
@@ -467,7 +467,7 @@ def camera_label(yaw, pitch=math.pi * 0.5, radius=2.7, device='cpu'):
     cam, _phi, _theta = vr.sample_camera_positions(device, n=1, r=radius, horizontal_mean=yaw + math.pi * 0.5,
                                                    vertical_mean=pitch, mode=None)
     c2w = vr.create_cam2world_matrix(-cam, cam, device=device).reshape(1, -1)
-    return torch.cat((c2w, torch.tensor(INTRINSICS, dtype=torch.float32, device=device).reshape(1, -1)), -1)
+    return torch.cat((c2w, vr.device_const(INTRINSICS, torch.float32, device).reshape(1, -1)), -1)
 
 
 class GraphedRenderer:

@@ -19,7 +19,7 @@ import torch
 
 from training import distributed_render as dr
 from training import triplane
-from training.volumetric_rendering import LookAtPoseSampler
+from training.volumetric_rendering import LookAtPoseSampler, device_const
 
 INTRINSICS = ((4.2647, 0, 0.5), (0, 4.2647, 0.5), (0, 0, 1))          # gen_videos.py:90
 
@@ -30,7 +30,7 @@ def sweep_pose(frame_idx: int, total_frames: int, lookat, radius: float = 2.7, y
     t = 2 * math.pi * frame_idx / total_frames
     cam2world = LookAtPoseSampler.sample(math.pi / 2 - yaw_range * np.sin(t), math.pi / 2 - 0.05 + pitch_range * np.cos(t),
                                          lookat, radius=radius, device=device)
-    intr = torch.tensor(INTRINSICS, dtype=torch.float32, device=device)
+    intr = device_const([v for row in INTRINSICS for v in row], torch.float32, device).reshape(3, 3)
     return torch.cat([cam2world.reshape(-1, 16), intr.reshape(-1, 9)], 1)
 
 
@@ -73,7 +73,7 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
 
     zs = torch.from_numpy(np.stack([np.random.RandomState(int(s)).randn(G.z_dim) for s in all_seeds])).to(device).float()
     front = LookAtPoseSampler.sample(math.pi / 2, math.pi / 2, lookat, radius=2.7, device=device)
-    c_front = torch.cat([front.reshape(-1, 16), torch.tensor(INTRINSICS, dtype=torch.float32, device=device).reshape(-1, 9)], 1)
+    c_front = torch.cat([front.reshape(-1, 16), device_const([v for row in INTRINSICS for v in row], torch.float32, device).reshape(-1, 9)], 1)
     ws = G.mapping(zs, c_front.repeat(len(zs), 1), truncation_psi=psi, truncation_cutoff=truncation_cutoff)
     ws = ws.reshape(grid_h, grid_w, num_keyframes, *ws.shape[1:]).cpu().numpy()
     total = num_keyframes * w_frames

@@ -34,6 +34,22 @@ def _init():
 
 # ---- small vector helpers ------------------------------------------------------------------------
 
+_consts = {}
+
+
+def device_const(values, dtype, device):
+    """A small read-only constant on `device`, uploaded ONCE per (values, dtype, device).  `torch.tensor(list, device='cuda')` is a
+    pageable host-to-device copy: the host blocks until the stream has drained, i.e. until the previous image has finished, and everything
+    the driver enqueues after it (the rest of the pose math, the synthesis pass) starts on an idle GPU.  The reference's
+    create_cam2world_matrix does exactly that once per pose (volumetric_rendering.py:199); here the pose helpers never synchronise.
+    Callers must not write to the returned tensor."""
+    key = (tuple(float(v) for v in values), dtype, str(device))
+    t = _consts.get(key)
+    if t is None:
+        t = _consts[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
+
+
 def transform_vectors(matrix: torch.Tensor, vectors4: torch.Tensor) -> torch.Tensor:
     """[M, M] applied to row vectors [N, M] -> [N, M]."""
     return vectors4 @ matrix.T
@@ -219,7 +235,7 @@ def sample_camera_positions(device, n=1, r=1, horizontal_stddev=0.3, vertical_st
 def create_cam2world_matrix(forward_vector, origin, device=None):
     """Look-along-`forward_vector` camera at `origin`, y-up: cam2world = T(origin) @ R([-left, up, -forward]) (reference :195-213)."""
     forward_vector = normalize_vecs(forward_vector)
-    world_up = torch.tensor([0, 1, 0], dtype=torch.float, device=device).expand_as(forward_vector)
+    world_up = device_const((0, 1, 0), torch.float, forward_vector.device if device is None else device).expand_as(forward_vector)
     left = normalize_vecs(torch.cross(world_up, forward_vector, dim=-1))
     up = normalize_vecs(torch.cross(forward_vector, left, dim=-1))
     n = forward_vector.shape[0]
