@@ -429,6 +429,41 @@ __device__ __forceinline__ void store_regions(u32x4* r, const Region (&R)[3], un
     const unsigned d = (lane == 0) ? bh[0] : (lane == 1) ? bh[1] : (lane == 2) ? bh[2] : m;
     if (lane < 4) r[lane] = u32x4{a, b, c, d};
 }
+// make_regions + store_regions for the producer / consumer kernel with the three planes on lanes 0-2 (round 5): the boxes, line counts and the
+// inside / size tests of the three regions are the same arithmetic on different axes, i.e. vector work; only the choice of the staged set and
+// the bases need all three line counts (three readlanes, ~25 scalar instructions).  As scalar code the whole table was ~100 dependent SALU
+// instructions of a wave whose chain every other wave of the workgroup waits for at the barrier.  Same table as make_regions, bit for bit.
+__device__ __forceinline__ void build_region_table(unsigned lo0, unsigned lo1, unsigned hi0, unsigned hi1, int W, int H, unsigned cap, u32x4* table, int lane) {
+    const unsigned xw_lo = lo0 & 0xffffu, yh_lo = lo0 >> 16, yw_lo = lo1 & 0xffffu, zh_lo = lo1 >> 16;
+    const unsigned xw_hi = hi0 & 0xffffu, yh_hi = hi0 >> 16, yw_hi = hi1 & 0xffffu, zh_hi = hi1 >> 16;
+    // plane 0: (x on W, y on H), plane 1: (y on W, z on H), plane 2: (x on W, z on H)
+    const unsigned x_lo = (lane == 1) ? yw_lo : xw_lo, x_hi = (lane == 1) ? yw_hi : xw_hi;
+    const unsigned y_lo = (lane == 0) ? yh_lo : zh_lo, y_hi = (lane == 0) ? yh_hi : zh_hi;
+    const unsigned bw = x_hi - x_lo + 2u, bh = y_hi - y_lo + 2u;
+    const unsigned segs = (lane == 1) ? (unsigned)TT_SEGS_B : (unsigned)TT_SEGS_A;
+    const unsigned lines = (__umul24(bw, bh) + 7u) & ~7u;
+    const bool inside = x_lo >= 1u && x_lo + bw - 2u <= (unsigned)(W - 1) && y_lo >= 1u && y_lo + bh - 2u <= (unsigned)(H - 1);
+    const unsigned l = (inside && lines <= segs * 32u) ? lines : cap + 1u;
+    const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)l, 0), l1 = (unsigned)__builtin_amdgcn_readlane((int)l, 1), l2 = (unsigned)__builtin_amdgcn_readlane((int)l, 2);
+    unsigned mask;
+    if (l0 + l1 + l2 <= cap) mask = 7u;
+    else {
+        const unsigned s01 = l0 + l1, s02 = l0 + l2, s12 = l1 + l2;
+        unsigned best = cap + 1u; mask = 0u;
+        if (s01 < best) { best = s01; mask = 3u; }
+        if (s02 < best) { best = s02; mask = 5u; }
+        if (s12 < best) { best = s12; mask = 6u; }
+        if (mask == 0u) {
+            if (l0 < best) { best = l0; mask = 1u; }
+            if (l1 < best) { best = l1; mask = 2u; }
+            if (l2 < best) { best = l2; mask = 4u; }
+        }
+    }
+    const unsigned b1 = (mask & 1u) ? l0 : 0u, b2 = b1 + ((mask & 2u) ? l1 : 0u);
+    const u32x4 row = (lane < 3) ? u32x4{x_lo, y_lo, bw, bh} : u32x4{0u, b1, b2, mask};
+    if (lane < 4) table[lane] = row;
+}
+
 __device__ __forceinline__ unsigned load_regions(const u32x4* r, Region (&R)[3]) {
     const u32x4 bases = r[3];
     const unsigned mask = uni(bases[3]);
@@ -581,6 +616,9 @@ triplane_sample_tile_kernel(const TileArgs p) {
 #ifndef IDE3D_PC_RWAVE
 #define IDE3D_PC_RWAVE 0                      // 1: wave 7 is a dedicated region builder R (F = waves 4-6) — measured 1-2 us SLOWER than 0 (T wave 0 builds the table beside its taps): R alone needs a whole iteration for the table chain and is last at the barrier instead
 #endif
+#ifndef IDE3D_PC_VECTABLE
+#define IDE3D_PC_VECTABLE 1                   // 1: the region table's per-plane arithmetic on lanes 0-2 (build_region_table); 0: all scalar (round 3)
+#endif
 #ifndef IDE3D_PC_DMA
 #define IDE3D_PC_DMA 1                        // 1: the F waves fill the line buffers by LDS-DMA (stage_dma) instead of loads + ds_write
 #endif
@@ -673,10 +711,13 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 const unsigned a1 = axis_index(oc[k][1], W) | (axis_index(oc[k][2], H) << 16);
                 lo0 = pk_min(lo0, a0); hi0 = pk_max(hi0, a0); lo1 = pk_min(lo1, a1); hi1 = pk_max(hi1, a1);
             }
-            Region R[3];
             wave_reduce_pk4(lo0, lo1, hi0, hi1);
-            const unsigned mask = make_regions(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, R);
-            store_regions(table, R, mask, lane);
+            if (IDE3D_PC_VECTABLE) build_region_table(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, table, lane);
+            else {
+                Region R[3];
+                const unsigned mask = make_regions(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, R);
+                store_regions(table, R, mask, lane);
+            }
         };
         // coordinates of the other three waves' samples (wave 0 only): sample t_id + 64 k of the chunk
         auto other_coord_ptr = [&](int k, unsigned step) {
@@ -757,10 +798,13 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                     const unsigned a1 = axis_index(cn[k][1], W) | (axis_index(cn[k][2], H) << 16);
                     lo0 = pk_min(lo0, a0); hi0 = pk_max(hi0, a0); lo1 = pk_min(lo1, a1); hi1 = pk_max(hi1, a1);
                 }
-                Region R[3];
                 wave_reduce_pk4(lo0, lo1, hi0, hi1);
-                const unsigned mask = make_regions(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, R);
-                store_regions(s_reg[(unsigned)it & 1u], R, mask, lane);
+                if (IDE3D_PC_VECTABLE) build_region_table(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, s_reg[(unsigned)it & 1u], lane);
+                else {
+                    Region R[3];
+                    const unsigned mask = make_regions(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, R);
+                    store_regions(s_reg[(unsigned)it & 1u], R, mask, lane);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -931,6 +975,9 @@ const char* triplane_tile_build_flags() {
 #endif
 #if IDE3D_PC_RWAVE
         "IDE3D_PC_RWAVE=1 "
+#endif
+#if !IDE3D_PC_VECTABLE
+        "IDE3D_PC_VECTABLE=0 "
 #endif
         ;
 }

@@ -40,7 +40,7 @@ def interpolate_ws(ws_keyframes: np.ndarray, w_frames: int, kind: str = 'cubic',
     x = np.arange(-k * wraps, k * (wraps + 1))
     y = np.tile(ws_keyframes, [wraps * 2 + 1, 1, 1])
     interp = scipy.interpolate.interp1d(x, y, kind=kind, axis=0)
-    return np.stack([interp(f / w_frames) for f in range(k * w_frames)]).astype(np.float32)
+    return interp(np.arange(k * w_frames) / w_frames).astype(np.float32)          # all frames in one evaluation (= the per-frame calls of gen_videos.py:127, bit for bit)
 
 
 def layout_u8(frames: torch.Tensor, grid_w: int, grid_h: int) -> torch.Tensor:

@@ -15,6 +15,9 @@ python scripts/kernel_rooflines.py --iters 20 --json $O/kernel_rooflines.json > 
 python scripts/bench_video.py 120 > $O/bench_video.json 2> $O/bench_video.err
 python scripts/bench_config4.py > $O/bench_config4_1gpu.json 2> $O/bench_config4.err
 python scripts/bench_shapes.py > $O/bench_shapes.json 2> $O/bench_shapes.err
+# the reference's gen_images.py loop verbatim (batch 1): G.synthesis replaying its own captured hipGraph, then the same loop with eager launches
+python scripts/bench_dropin.py 90 > $O/bench_dropin.json 2> $O/bench_dropin.err
+python scripts/bench_dropin.py 90 --eager >> $O/bench_dropin.json 2>> $O/bench_dropin.err
 python scripts/bench_encoder.py > $O/bench_encoder.json 2> $O/bench_encoder.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-extra --no-arith-sweep > $O/bench_under_rocprof.json 2> $O/prof_bench.err )
 python scripts/step_breakdown.py $O/prof_bench $O/bench_step_breakdown.json > /dev/null 2>&1
