@@ -671,8 +671,10 @@ def main():
                     fl = sum(r['algorithmic_flops'] * n for r in dom for t, n in per_step.items() if t in r['name'])
                     peak = dom[0]['peak']
                     pm = kernel_rooflines._pmc_notes()
-                    busy = next((v for k, v in pm.items() if k.startswith('modconv_split_kernel<0, 1, 16')), None)
-                    out['roofline_step'] = {'kernel': 'modconv_split_kernel<0,1,16,3,2,8,0> (3x3 stride-1, 64^2..256^2 layers)', 'bound': f'mfma:{arith}', 'launches_per_step': 4,
+                    # template arguments <MODE, BIG, tile rows, PARTS, weight buffers, waves, F16>: bf16x6 = 3 pieces, f16x3 = 2 fp16 pieces, bf16x3 = 2 bf16 pieces
+                    kname = {'bf16x6': 'modconv_split_kernel<0, 1, 16, 3, 2, 8, 0>', 'f16x3': 'modconv_split_kernel<0, 1, 16, 2, 2, 8, 1>', 'bf16x3': 'modconv_split_kernel<0, 1, 16, 2, 2, 8, 0>'}[arith]
+                    busy = pm.get(kname)
+                    out['roofline_step'] = {'kernel': kname.replace(', ', ',') + ' (3x3 stride-1, 64^2..256^2 layers)', 'bound': f'mfma:{arith}', 'launches_per_step': 4,
                                             'us_per_step': r3(us, 1), 'share_of_step': r3(us / (med / args.steps * 1e6), 3), 'achieved': r3(fl / us / 1e6, 1), 'peak': r3(peak, 1),
                                             'unit': 'TFLOP/s', 'frac': r3(fl / us / 1e6 / peak, 3),
                                             'mfma_busy_frac': None if busy is None else busy['mfma_busy_frac'], 'mfma_busy_measured_in_this_run': False}
