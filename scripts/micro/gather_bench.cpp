@@ -117,6 +117,19 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        if (dbg_fn dbgr = (dbg_fn)dlsym(lib, "ide3d_debug_tt_pc_r")) {
+            static unsigned long long v[32][8];
+            if (dbgr(&v[0][0]) == 0 && v[1][0]) {
+                printf("  region-builder wave (IDE3D_PC_RWAVE builds): [copy + issue next loads, index arithmetic, reduce, table, barrier wait] total\n");
+                for (int it = 0; it < 24; ++it) {
+                    const unsigned long long* r = v[it];
+                    if (!r[0]) continue;
+                    printf("  %2d:", it);
+                    for (int i = 0; i < 5; ++i) printf(" %6lld", (long long)(r[i + 1] - r[i]));
+                    printf("  total %6lld\n", (long long)(r[5] - r[0]));
+                }
+            }
+        }
         if (dbg_fn dbgw = (dbg_fn)dlsym(lib, "ide3d_debug_tt_wg")) {
             static unsigned long long w[1024][4];
             if (dbgw(&w[0][0]) == 0 && w[0][0]) {
