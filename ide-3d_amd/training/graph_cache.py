@@ -130,6 +130,7 @@ class _ModuleGraphs:
         self.entries = collections.OrderedDict()     # signature -> _Captured (LRU order)
         self.seen = {}                               # signature -> eager sightings so far
         self.stamp = None
+        self.lock = threading.RLock()                # one thread at a time per module: a replay and the copy-out of its static outputs are one step
 
     def clear(self):
         self.entries.clear()
@@ -186,7 +187,14 @@ def run(module, impl, ws, c, render_params, noise_mode, flags, force_fp32, ray_j
     from training import networks
     cache = _caches.get(module)
     if cache is None:
-        cache = _caches[module] = _ModuleGraphs()
+        cache = _caches.setdefault(module, _ModuleGraphs())
+    with cache.lock:
+        return _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, force_fp32, ray_jitter, cached_planes, kind)
+
+
+def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, force_fp32, ray_jitter, cached_planes, kind):
+    from torch_utils import hip_plugin
+    from training import networks
     sp = module.spec
     n = ws.shape[0]
     steps = render_params.get('num_steps') or sp.num_steps

@@ -249,3 +249,39 @@ def test_reference_gen_images_loop_full_size_replay_equals_eager(G_full, gpu_dev
                 img, seg = G.synthesis(ws, c=_cams([yaw], gpu_device), render_params=rp, noise_mode='const', return_seg=True)
                 assert torch.equal(img, imgs[k]) and torch.equal(seg, segs[k]), (seed, yaw)
     assert graph_cache.stats(G.synthesis)['graphs'] == 1
+
+
+def test_two_threads_on_their_own_streams_share_the_module(G, gpu_device):
+    """Two host threads render with ONE generator on two streams (the eager path supports it: per-thread prefetch tables, per-stream
+    workspaces).  The stream is part of the signature, so each thread captures and replays its own graph with its own static buffers and
+    memory pool; the module's cache is entered by one thread at a time."""
+    import threading
+    from training import graph_cache
+    graph_cache.reset(G.synthesis)
+    c = _cams([0.1], gpu_device)
+    ws = [_ws(G, [20 + k], gpu_device) for k in range(2)]
+    with graph_cache.disabled():
+        want = [G.synthesis(w, c=c, ray_jitter=False, return_seg=True) for w in ws]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=gpu_device)
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(6):
+                    out = G.synthesis(ws[k], c=c, ray_jitter=False, return_seg=True)
+                st.synchronize()
+            got[k] = out
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]), f'thread {k}'
+    assert graph_cache.stats(G.synthesis)['graphs'] == 2
