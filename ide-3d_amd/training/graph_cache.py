@@ -341,7 +341,8 @@ def _capture(module, impl, ws, c, ray_jitter, cached_planes, steps, sig):
     pool = _pools.get(pool_key)
     if pool is None:
         pool = _pools[pool_key] = torch.cuda.graph_pool_handle()
-    with torch.no_grad(), scope, disabled(), torch.cuda.graph(graph, stream=stream, pool=pool):
+    # thread_local: another host thread of the application (a data loader, a second renderer) may keep calling the runtime while this one captures
+    with torch.no_grad(), scope, disabled(), torch.cuda.graph(graph, stream=stream, pool=pool, capture_error_mode='thread_local'):
         ent.out = impl(ent.ws, ent.c, jit_arg, cached_planes)
     ent.graph = graph
     # the memory the graph reads through raw pointers stays allocated for as long as the graph: the tensors themselves and aliases of their
