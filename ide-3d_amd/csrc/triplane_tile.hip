@@ -639,7 +639,7 @@ triplane_sample_tile_kernel(const TileArgs p) {
 #ifndef IDE3D_PC_TRACE_BLOCK
 #define IDE3D_PC_TRACE_BLOCK 100
 #endif
-__device__ unsigned long long g_pc_dbg[4][32][8];          // roles T, F, B, R (region-builder wave of IDE3D_PC_RWAVE builds)
+__device__ unsigned long long g_pc_dbg[3][32][8];
 __device__ unsigned long long g_pc_wg[1024][4];          // per workgroup (B wave 0): shader cycles entry -> end, 100 MHz clock at entry / end, staged-plane masks seen
 #define IDE3D_PCT(role, k) if (blockIdx.x == IDE3D_PC_TRACE_BLOCK && lane == 0 && ridx == 0 && it >= 0 && it < 32) g_pc_dbg[role][it][(k)] = __builtin_readcyclecounter();
 #else
@@ -698,7 +698,6 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
         const unsigned row_a = (img * (unsigned)p.rays_per_image + ray_a) * (unsigned)p.steps;
         const unsigned last_step = (unsigned)p.steps - 1u;
         auto coord_ptr = [&](unsigned step) { return p.coords + (size_t)(row_a + min(step + ds, last_step)) * 3; };
-        const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.planes, 0, (int)p.group_bytes, 0x00020000);      // IDE3D_PC_RWAVE == 2: the tap waves issue a share of the fill
         // Region table of a chunk: wave 0 alone builds it, from the footprint origins of ALL 256 samples — its own 64 from the taps it
         // sets up anyway, the other 192 from the index half of the tap arithmetic on coordinates it loads itself (3 more samples per
         // lane).  No exchange between the T waves: an LDS round trip takes hundreds of cycles while eight blending waves keep the LDS
@@ -745,12 +744,6 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 const unsigned buf = (unsigned)(it + 1) & 1u;
                 Region R[3];
                 const unsigned mask = load_regions(s_reg[buf], R);
-                if (IDE3D_PC_RWAVE == 2) {          // segments s % 7 == ridx of every staged region (the fetching waves take 4, 5, 6): in flight while this wave works on
-                    unsigned char* const s_lines = s_lines0 + buf * (PC_CAP * TT_LINE);
-                    if (R[0].staged) stage_dma<(TT_SEGS_A * 4 + 6) / 7, 7>(p, rsrc_t, R[0], 0, img_bytes, ridx, slot, ch_bytes, s_lines);
-                    if (R[1].staged) stage_dma<(TT_SEGS_B * 4 + 6) / 7, 7>(p, rsrc_t, R[1], 1, img_bytes, ridx, slot, ch_bytes, s_lines);
-                    if (R[2].staged) stage_dma<(TT_SEGS_A * 4 + 6) / 7, 7>(p, rsrc_t, R[2], 2, img_bytes, ridx, slot, ch_bytes, s_lines);
-                }
                 write_tap_entry(p, t_hold, R, img_bytes, s_tap0[buf * 256u + t_id]);
                 if (t_id == 0) s_meta[buf] = u32x4{mask, R[0].bw, R[1].bw, R[2].bw};
             }
@@ -773,7 +766,6 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 if (!IDE3D_PC_RWAVE && ridx == 0) build_regions(t_hold, oc_now, s_reg[(unsigned)it & 1u]);
             }
             IDE3D_PCT(0, 3)
-            if (IDE3D_PC_RWAVE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the fill has landed
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             IDE3D_PCT(0, 4)
         }
@@ -793,14 +785,12 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const float* q = sample_ptr(k, step_begin); c[k][0] = q[0]; c[k][1] = q[1]; c[k][2] = q[2]; }
         for (int it = -2; it < nch; ++it) {
-            { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 0) }
             if (it + 2 < nch) {
                 float cn[4][3];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { cn[k][0] = c[k][0]; cn[k][1] = c[k][1]; cn[k][2] = c[k][2]; }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const float* q = sample_ptr(k, step_begin + (unsigned)(it + 3) * TT_DS); c[k][0] = q[0]; c[k][1] = q[1]; c[k][2] = q[2]; }
-                { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 1) }
                 unsigned lo0 = 0xffffffffu, lo1 = 0xffffffffu, hi0 = 0u, hi1 = 0u;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -808,9 +798,7 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                     const unsigned a1 = axis_index(cn[k][1], W) | (axis_index(cn[k][2], H) << 16);
                     lo0 = pk_min(lo0, a0); hi0 = pk_max(hi0, a0); lo1 = pk_min(lo1, a1); hi1 = pk_max(hi1, a1);
                 }
-                { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 2) }
                 wave_reduce_pk4(lo0, lo1, hi0, hi1);
-                { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 3) }
                 if (IDE3D_PC_VECTABLE) build_region_table(lo0, lo1, hi0, hi1, W, H, (unsigned)PC_CAP, s_reg[(unsigned)it & 1u], lane);
                 else {
                     Region R[3];
@@ -818,9 +806,7 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                     store_regions(s_reg[(unsigned)it & 1u], R, mask, lane);
                 }
             }
-            { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 4) }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            { const int ridx = 0; (void)ridx; IDE3D_PCT(3, 5) }
         }
     } else if (wid < 8) {
         // ---------------------------------------------------------------- F: region loads + LDS fill ------------------------
@@ -836,13 +822,7 @@ triplane_sample_tile_pc_kernel(const TileArgs p) {
                 // (Tried: the F waves touching one dword per line of the NOT staged planes, to pull them into L1 / L2 ahead of the blending
                 // waves' buffer loads — 64 separate lines per load instruction made F the slowest role: 73.5 vs 70.3 us.)
                 int n0 = 0, n1 = 0, n2 = 0;
-                if (IDE3D_PC_DMA && IDE3D_PC_RWAVE == 2) {     // seven issuers: the four tap waves (0-3) and these three (4-6)
-                    if (R[0].staged) stage_dma<(TT_SEGS_A * 4 + 6) / 7, 7>(p, rsrc, R[0], 0, img_bytes, 4 + ridx, slot, ch_bytes, s_lines);
-                    if (R[1].staged) stage_dma<(TT_SEGS_B * 4 + 6) / 7, 7>(p, rsrc, R[1], 1, img_bytes, 4 + ridx, slot, ch_bytes, s_lines);
-                    if (R[2].staged) stage_dma<(TT_SEGS_A * 4 + 6) / 7, 7>(p, rsrc, R[2], 2, img_bytes, 4 + ridx, slot, ch_bytes, s_lines);
-                    IDE3D_PCT(1, 1)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (IDE3D_PC_DMA && IDE3D_PC_RWAVE) {          // three fetching waves (4-6)
+                if (IDE3D_PC_DMA && IDE3D_PC_RWAVE) {          // three fetching waves (4-6)
                     if (R[0].staged) stage_dma<(TT_SEGS_A * 4 + 2) / 3, 3>(p, rsrc, R[0], 0, img_bytes, ridx, slot, ch_bytes, s_lines);
                     if (R[1].staged) stage_dma<(TT_SEGS_B * 4 + 2) / 3, 3>(p, rsrc, R[1], 1, img_bytes, ridx, slot, ch_bytes, s_lines);
                     if (R[2].staged) stage_dma<(TT_SEGS_A * 4 + 2) / 3, 3>(p, rsrc, R[2], 2, img_bytes, ridx, slot, ch_bytes, s_lines);
@@ -979,9 +959,6 @@ extern "C" int ide3d_debug_tt_wg(unsigned long long* host) {
 extern "C" int ide3d_debug_tt_pc(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ide3d::g_pc_dbg), sizeof(unsigned long long) * 3 * 32 * 8);
 }
-extern "C" int ide3d_debug_tt_pc_r(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ide3d::g_pc_dbg), sizeof(unsigned long long) * 32 * 8, sizeof(unsigned long long) * 3 * 32 * 8);
-}
 #endif
 
 namespace ide3d {
@@ -997,7 +974,7 @@ const char* triplane_tile_build_flags() {
         "IDE3D_PC_DMA=0 "
 #endif
 #if IDE3D_PC_RWAVE
-        "IDE3D_PC_RWAVE=" IDE3D_STR(IDE3D_PC_RWAVE) " "
+        "IDE3D_PC_RWAVE=1 "
 #endif
 #if !IDE3D_PC_VECTABLE
         "IDE3D_PC_VECTABLE=0 "
