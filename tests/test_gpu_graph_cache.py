@@ -285,3 +285,34 @@ def test_two_threads_on_their_own_streams_share_the_module(G, gpu_device):
     for k in range(2):
         assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]), f'thread {k}'
     assert graph_cache.stats(G.synthesis)['graphs'] == 2
+
+
+def test_replays_do_not_grow_memory_and_dropped_graphs_release_theirs(G, gpu_device, monkeypatch):
+    """300 calls over four alternating signatures (LRU bound 3: one of them is evicted and captured again, over and over) leave the
+    allocator where 60 calls left it; dropping the graphs gives their memory back."""
+    from training import graph_cache
+    graph_cache.reset(G.synthesis)
+    monkeypatch.setenv('IDE3D_AUTO_GRAPH_MAX', '3')
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(gpu_device)
+    c = _cams([0.0], gpu_device)
+    wss = {n: _ws(G, list(range(n)), gpu_device) for n in (1, 2, 3, 4)}
+
+    def burst(k):
+        for i in range(k):
+            n = 1 + i % 4
+            out = G.synthesis(wss[n], c=c.repeat(n, 1), ray_jitter=False, return_seg=True)
+        del out
+        torch.cuda.synchronize()
+        return torch.cuda.memory_allocated(gpu_device)
+
+    m60 = burst(60)
+    m300 = burst(240)
+    assert graph_cache.stats(G.synthesis)['graphs'] == 3
+    assert m300 <= m60 + (1 << 20), f'allocator grew by {(m300 - m60) / 2**20:.1f} MiB over 240 more calls'
+    graph_cache.reset(G.synthesis)
+    import gc; gc.collect()
+    torch.cuda.synchronize()
+    held = m300 - base
+    freed = m300 - torch.cuda.memory_allocated(gpu_device)
+    assert freed >= 0.5 * held > 0, (held, freed)
