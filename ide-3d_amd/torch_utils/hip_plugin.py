@@ -323,6 +323,48 @@ def _stream(t):
     return ctypes.c_void_p(_stream_handle(t.device))
 
 
+# ---- streams of our own ----------------------------------------------------------------------------------------------------------
+# `torch.cuda.Stream()` hands out one of 32 pooled handles per device, round-robin: the 33rd stream an application (or this library) asks
+# for IS the first one again.  A hipGraph capture whose capture stream happens to be the style side stream, or a stream the caller renders
+# on, is malformed (round 5: a host-side segfault in hipGraphLaunch at the 33rd capture of a process, scripts/micro/r5_graph_churn.py).
+# The streams this library forks work to - the capture stream of training/graph_cache.py and triplane.GraphedRenderer, the style
+# prefetch side stream - are therefore created from the HIP runtime directly, once per (device, purpose), and never collide with a pooled one.
+_private_streams = {}
+
+
+def _hip_runtime():
+    paths = _hip_runtimes_mapped()
+    if len(paths) != 1:
+        raise RuntimeError(f'expected exactly one HIP runtime mapped in this process, found {sorted(paths)}')
+    rt = ctypes.CDLL(next(iter(paths)))          # the path that is already mapped: the same instance torch uses
+    rt.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    rt.hipStreamCreateWithFlags.restype = ctypes.c_int
+    return rt
+
+
+def private_stream(device, purpose):
+    """A `torch.cuda.ExternalStream` around a HIP stream created for (device, purpose) and kept for the life of the process."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, purpose)
+    st = _private_streams.get(key)
+    if st is None:
+        with _lock:
+            st = _private_streams.get(key)
+            if st is None:
+                torch.cuda.init()
+                h = ctypes.c_void_p()
+                with torch.cuda.device(idx):
+                    rc = _hip_runtime().hipStreamCreateWithFlags(ctypes.byref(h), 1)          # hipStreamNonBlocking, like torch's pooled streams
+                if rc != 0 or not h.value:
+                    raise RuntimeError(f'hipStreamCreateWithFlags failed ({rc})')
+                st = _private_streams[key] = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
+    return st
+
+
+capture_lock = threading.RLock()          # one hipGraph capture at a time per process (they share the capture stream of their device)
+
+
 class _NoGuard:
     def __enter__(self):
         return self

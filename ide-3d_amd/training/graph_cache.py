@@ -133,6 +133,8 @@ class _ModuleGraphs:
         self.lock = threading.RLock()                # one thread at a time per module: a replay and the copy-out of its static outputs are one step
 
     def clear(self):
+        if self.entries:          # replays may still be running (and reading the graphs' workspaces): let them finish before anything is freed
+            torch.cuda.synchronize(next(iter(self.entries.values())).ws.device)
         self.entries.clear()
         self.seen.clear()
 
@@ -249,7 +251,8 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
         STATS['eager'] += 1
         return impl(ws, c, ray_jitter, cached_planes)
     try:
-        ent = _capture(module, impl, ws, c, ray_jitter, cached_planes, steps, sig)
+        with hip_plugin.capture_lock:
+            ent = _capture(module, impl, ws, c, ray_jitter, cached_planes, steps, sig)
     except Exception as e:      # never a silent slow path: say so once per signature, then stay eager for it
         warnings.warn(f'ide3d graph_cache: capture of G.synthesis failed ({type(e).__name__}: {e}); this call signature stays eager')
         cache.seen[sig] = -(1 << 60)
@@ -258,6 +261,7 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
     cache.entries[sig] = ent
     cache.seen.pop(sig, None)
     while len(cache.entries) > max(1, _env_int('IDE3D_AUTO_GRAPH_MAX', 6)):
+        torch.cuda.synchronize(ws.device)              # replays of the graph that is about to go may still be running; so may readers of its workspaces
         cache.entries.popitem(last=False)
     STATS['capture'] += 1
     STATS['replay'] += 1
@@ -329,7 +333,7 @@ def _capture(module, impl, ws, c, ray_jitter, cached_planes, steps, sig):
             ent.jitter.fill_(0.5)         # the warm-up's values are irrelevant; no draw is taken from the caller's generator
     jit_arg = False if ent.jitter is None else ent.jitter
     main = torch.cuda.current_stream(dev)
-    stream = torch.cuda.Stream(device=dev)
+    stream = hip_plugin.private_stream(dev, 'graph capture')          # never one of torch's pooled handles (hip_plugin.private_stream)
     stream.wait_stream(main)
     scope = hip_plugin.workspace_scope(ent)
     with torch.cuda.stream(stream), torch.no_grad(), scope, disabled():
@@ -337,10 +341,12 @@ def _capture(module, impl, ws, c, ray_jitter, cached_planes, steps, sig):
     main.wait_stream(stream)
     torch.cuda.synchronize(dev)
     graph = torch.cuda.CUDAGraph()
-    pool_key = (dev.index, hip_plugin._stream_handle(dev))
-    pool = _pools.get(pool_key)
-    if pool is None:
-        pool = _pools[pool_key] = torch.cuda.graph_pool_handle()
+    pool = None
+    if os.environ.get('IDE3D_AUTO_GRAPH_SHARED_POOL', '0') == '1':
+        pool_key = (dev.index, hip_plugin._stream_handle(dev))
+        pool = _pools.get(pool_key)
+        if pool is None:
+            pool = _pools[pool_key] = torch.cuda.graph_pool_handle()
     # thread_local: another host thread of the application (a data loader, a second renderer) may keep calling the runtime while this one captures
     with torch.no_grad(), scope, disabled(), torch.cuda.graph(graph, stream=stream, pool=pool, capture_error_mode='thread_local'):
         ent.out = impl(ent.ws, ent.c, jit_arg, cached_planes)

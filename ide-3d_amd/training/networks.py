@@ -103,7 +103,8 @@ def _prefetch_table():
 def side_stream(device):
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        from torch_utils import hip_plugin
+        st = _side_streams[device] = hip_plugin.private_stream(device, 'style prefetch')      # not a pooled handle: it must never be the stream a pass is captured on
     return st
 
 

@@ -526,7 +526,8 @@ class GraphedRenderer:
                 self.jitter.copy_(ray_jitter)
         self._fixed_jitter = ray_jitter is not None and ray_jitter is not False
         self.graph = None
-        stream = torch.cuda.Stream(device=device)
+        from torch_utils import hip_plugin
+        stream = hip_plugin.private_stream(device, 'graph capture')          # never one of torch's 32 pooled handles (hip_plugin.private_stream)
         stream.wait_stream(torch.cuda.current_stream(device))
         # Every launch of the warm-up and of the capture takes its scratch memory (packed weights, split-K partials, the mapping
         # kernel's barrier counter) from workspaces owned by THIS object (hip_plugin.workspace_scope), not by a stream handle that
@@ -538,7 +539,7 @@ class GraphedRenderer:
         torch.cuda.current_stream(device).wait_stream(stream)
         torch.cuda.synchronize(device)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), scope, torch.cuda.graph(graph, stream=stream):
+        with hip_plugin.capture_lock, torch.no_grad(), scope, torch.cuda.graph(graph, stream=stream):
             self.out = self._body()
         self.graph = graph
         self._stream = stream
