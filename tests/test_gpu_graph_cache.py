@@ -314,3 +314,32 @@ def test_replays_do_not_grow_memory_and_dropped_graphs_release_theirs(G, gpu_dev
     import gc; gc.collect()
     torch.cuda.synchronize()
     assert graph_cache.stats(G.synthesis)['graphs'] == 0 and torch.cuda.memory_allocated(gpu_device) <= m300
+
+
+def test_more_captures_than_torch_has_pooled_streams(G, gpu_device, monkeypatch):
+    """Regression (round 5): `torch.cuda.Stream()` hands out 32 pooled handles round-robin, so the 33rd capture of a process used to be
+    captured on a handle that was already the style side stream (or an older graph's capture stream): a malformed capture and a host-side
+    segfault in hipGraphLaunch.  Captures and the side stream now use streams of the library's own (`hip_plugin.private_stream`): 40
+    capture / evict cycles beside a graph that stays alive, every replay still equal to the eager pass."""
+    from torch_utils import hip_plugin
+    from training import graph_cache
+    graph_cache.reset(G.synthesis)
+    monkeypatch.setenv('IDE3D_AUTO_GRAPH_MAX', '2')
+    c = _cams([0.0], gpu_device)
+    keep_ws = _ws(G, [1, 2, 3, 4, 5], gpu_device)
+    with graph_cache.disabled():
+        keep_want = G.synthesis(keep_ws, c=c.repeat(5, 1), ray_jitter=False)
+    wss = {n: _ws(G, list(range(n)), gpu_device) for n in (1, 2, 3)}
+    with graph_cache.disabled():
+        want = {n: G.synthesis(wss[n], c=c.repeat(n, 1), ray_jitter=False) for n in (1, 2, 3)}
+    caps = graph_cache.STATS['capture']
+    i = 0
+    while graph_cache.STATS['capture'] - caps < 40:
+        n = 1 + i % 3; i += 1
+        assert torch.equal(G.synthesis(wss[n], c=c.repeat(n, 1), ray_jitter=False), want[n])
+        if i % 3 == 0:          # the five-image signature is used often enough to stay in the LRU pair: its graph outlives 40 captures
+            assert torch.equal(G.synthesis(keep_ws, c=c.repeat(5, 1), ray_jitter=False), keep_want)
+    assert i < 400
+    s1, s2 = hip_plugin.private_stream(gpu_device, 'graph capture'), hip_plugin.private_stream(gpu_device, 'style prefetch')
+    pooled = {torch.cuda.Stream(device=gpu_device).cuda_stream for _ in range(40)}
+    assert s1.cuda_stream != s2.cuda_stream and s1.cuda_stream not in pooled and s2.cuda_stream not in pooled
