@@ -130,6 +130,7 @@ class _ModuleGraphs:
         self.entries = collections.OrderedDict()     # signature -> _Captured (LRU order)
         self.seen = {}                               # signature -> eager sightings so far
         self.stamp = None
+        self.evictions = 0                           # LRU evictions so far: every one doubles the sightings a new signature needs (no capture thrash)
         self.lock = threading.RLock()                # one thread at a time per module: a replay and the copy-out of its static outputs are one step
 
     def clear(self):
@@ -137,6 +138,7 @@ class _ModuleGraphs:
             torch.cuda.synchronize(next(iter(self.entries.values())).ws.device)
         self.entries.clear()
         self.seen.clear()
+        self.evictions = 0
 
 
 def _out_tensors(out):
@@ -243,8 +245,10 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
         STATS['ineligible:' + why] += 1
         return impl(ws, c, ray_jitter, cached_planes)
 
+    # A capture costs ~3 passes + a device synchronisation.  A caller that rotates through more signatures than the LRU holds would pay it
+    # over and over: every eviction doubles the number of eager sightings the next new signature needs (1, 2, 4, ... 64).
     seen = cache.seen.get(sig, 0)
-    if seen < _env_int('IDE3D_AUTO_GRAPH_AFTER', 1):
+    if seen < _env_int('IDE3D_AUTO_GRAPH_AFTER', 1) << min(cache.evictions, 6):
         if len(cache.seen) > 256:
             cache.seen.clear()
         cache.seen[sig] = seen + 1
@@ -263,6 +267,7 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
     while len(cache.entries) > max(1, _env_int('IDE3D_AUTO_GRAPH_MAX', 6)):
         torch.cuda.synchronize(ws.device)              # replays of the graph that is about to go may still be running; so may readers of its workspaces
         cache.entries.popitem(last=False)
+        cache.evictions += 1
     STATS['capture'] += 1
     STATS['replay'] += 1
     return _replay(ent, ws, c, ray_jitter, cached_planes)
