@@ -291,6 +291,8 @@ def _ineligible(module, ws, c, render_params, noise_mode, ray_jitter, cached_pla
         return 'switched off'
     if not (torch.is_tensor(ws) and ws.is_cuda and ws.ndim == 3 and (c is None or (torch.is_tensor(c) and c.device == ws.device and c.ndim == 2))):
         return 'not device tensors'
+    if ws.device.index is not None and ws.device.index != torch.cuda.current_device():
+        return 'tensors on a device that is not the current one'          # the eager launches guard the device per call; a replay would not
     if torch.cuda.is_current_stream_capturing():
         return 'capture in progress'
     if noise_mode not in ('const', 'none'):
