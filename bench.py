@@ -487,10 +487,8 @@ def main():
             dist.barrier()
         sync()
 
-    # The roofline kernel of BASELINE's metric (the isolated tri-plane gather) is measured FIRST, on the GPU as the job finds it (its own 400
-    # warm launches bring it to that kernel's sustained clocks), and once more after everything else: boxes that have just run a minute of
-    # matrix-core load clock this 66-us kernel 5-8 % lower (round 5: 66.1 us at the start of a run, 72.1 us behind the test suite + the sweep).
-    # `roofline` is the first measurement; the second travels beside it (`after_sustained_load`).
+    # The roofline kernel of BASELINE's metric (the isolated tri-plane gather) is measured first thing, on the GPU as the job finds it, and once
+    # more after everything else; see below where the line is assembled.
     rf_first = bench_gather(device) if (not cpu and rank == 0 and not args.no_roofline) else None
 
     for i in range(args.warmup):
@@ -651,14 +649,19 @@ def main():
             out['by_conv_arithmetic'] = {k: {'frames_per_s': r3(v['frames_per_s'], 1), 'parity_ok': v.get('parity_ok')} for k, v in sweep_full.items()}
             out['value_fp32_exact'] = r3(sweep_full['fp32']['frames_per_s'], 2)      # exact-fp32 products (v_mfma_f32_32x32x2_f32) in every convolution
         if not cpu and not args.no_roofline:
-            rf, rf_late = rf_first, bench_gather(device)
+            # two measurements of the same kernel in one run (start / end): their spread is the box's clock state, not the kernel (round 5: 69.8
+            # then 65.6 us on one box, 66.1 then 72.1 on another).  `roofline` is the FASTER of the two — the usual estimator of a kernel's
+            # own time under noise — and both travel in the line.
+            rf_late = bench_gather(device)
+            both = {'at_start': {'avg_launch_us': r3(rf_first['avg_launch_us'], 2), 'frac': r3(rf_first['frac'], 4)},
+                    'after_sustained_load': {'avg_launch_us': r3(rf_late['avg_launch_us'], 2), 'frac': r3(rf_late['frac'], 4)}}
+            rf = rf_first if rf_first['avg_launch_us'] <= rf_late['avg_launch_us'] else rf_late
             full['roofline'] = rf
-            full['roofline_after_sustained_load'] = rf_late
+            full['roofline_both'] = {'at_start': rf_first, 'after_sustained_load': rf_late}
             out['roofline'] = {'kernel': rf['kernel'], 'bound': 'hbm', 'achieved': r3(rf['achieved'], 1), 'peak': rf['peak'], 'unit': 'GB/s',
                                'frac': r3(rf['frac'], 4), 'traffic': rf['traffic'], 'traffic_measured_in_this_run': False,
                                'bytes_per_launch': rf['bytes_per_launch'], 'avg_launch_us': r3(rf['avg_launch_us'], 2), 'timed_launches': rf['timed_launches'],
-                               'measured': 'first thing in the run (after 400 warm launches)',
-                               'after_sustained_load': {'avg_launch_us': r3(rf_late['avg_launch_us'], 2), 'frac': r3(rf_late['frac'], 4)}}
+                               'measured': 'twice in this run (first thing, and after everything else), 400 warm launches each; the faster one is reported', **both}
         if not cpu and world == 1 and not args.no_roofline_extra:
             try:
                 sys.path.insert(0, os.path.join(ROOT, 'scripts'))

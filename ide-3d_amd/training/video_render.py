@@ -11,6 +11,7 @@ time (`kind='cubic'`, `wraps` periodic copies), one look-at camera per frame swe
 """
 
 import math
+import weakref
 from typing import Iterable, Iterator, Sequence, Tuple
 
 import numpy as np
@@ -41,6 +42,23 @@ def interpolate_ws(ws_keyframes: np.ndarray, w_frames: int, kind: str = 'cubic',
     y = np.tile(ws_keyframes, [wraps * 2 + 1, 1, 1])
     interp = scipy.interpolate.interp1d(x, y, kind=kind, axis=0)
     return interp(np.arange(k * w_frames) / w_frames).astype(np.float32)          # all frames in one evaluation (= the per-frame calls of gen_videos.py:127, bit for bit)
+
+
+_plane_buffers = weakref.WeakKeyDictionary()          # synthesis module -> the pair of buffers its static tri-planes are kept in
+
+
+def _static_plane_buffers(synthesis, planes):
+    """The job's static tri-planes, copied into buffers that live as long as the generator: `G.synthesis` reads cached tri-planes in place and
+    keys its captured pass on their addresses (training/graph_cache.py), so the next video job of this generator replays the pass the previous
+    one captured instead of capturing its own (a capture costs ~3 passes + a device synchronisation: 10 % of a 120-frame job)."""
+    if not planes[0].is_cuda:
+        return planes
+    bufs = _plane_buffers.get(synthesis)
+    if bufs is None or any(b.shape != t.shape or b.stride() != t.stride() or b.device != t.device or b.dtype != t.dtype for b, t in zip(bufs, planes)):
+        bufs = _plane_buffers[synthesis] = tuple(torch.empty_like(t) for t in planes)          # empty_like keeps the channels-last strides
+    for b, t in zip(bufs, planes):
+        b.copy_(t)
+    return bufs
 
 
 def layout_u8(frames: torch.Tensor, grid_w: int, grid_h: int) -> torch.Tensor:
@@ -84,7 +102,7 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
     static = cache_static_planes and num_keyframes == 1 and bool(torch.allclose(ws_frames, ws_frames[:, :1].expand_as(ws_frames), atol=1e-5))
     planes = None
     if static:
-        planes = G.synthesis.planes(ws_frames[:, 0], noise_mode=noise_mode)
+        planes = _static_plane_buffers(G.synthesis, G.synthesis.planes(ws_frames[:, 0], noise_mode=noise_mode))
     palette = dr.palette_tensor(G.synthesis.seg_channels, device)
     for frame_idx in range(total):
         c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)
