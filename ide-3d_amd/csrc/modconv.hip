@@ -184,7 +184,8 @@ __device__ __forceinline__ void amax_commit(float* y_amax, int n, float v, bool)
     if (v > 0.f) amax_raise(y_amax, n, v);
 }
 
-template <int MODE, int TI, int PH, int PW, int NWV, int NCLS, int MTW, int NTW, int BM, int SCRATCH>
+// ROWPAR >= 0 (all-class transposed form): acc holds the two column classes of output rows 2 gy + ROWPAR only
+template <int MODE, int TI, int PH, int PW, int NWV, int NCLS, int MTW, int NTW, int BM, int SCRATCH, int ROWPAR = -1>
 __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, float* __restrict__ partial, const ConvGeom& g,
                                                f32x16 (&acc)[NCLS][MTW][NTW], float* s_w, int mb, int n0, int y0, int x0, int split, int cls,
                                                int wm, int wn, int lp, const float* __restrict__ row_unscale = nullptr, float x_unscale = 1.f,
@@ -230,6 +231,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
     // two x-parity classes of the all-class transposed convolution interleaved); a lane then takes 4 consecutive output
     // pixels of ONE channel, finishes them (one d / b pair, one 16-byte noise load) and stores 16 bytes.
     constexpr int QX = (MODE == MODE_TCONV3A) ? 2 : 1, QY = NCLS / QX;
+    static_assert(ROWPAR < 0 || (MODE == MODE_TCONV3A && NCLS == 2), "one row parity = two column classes");
     constexpr int TW = 32 * QX, TP = TW + 8;                     // staged row: floats, pitch (rows r and r + 4 on disjoint banks)
     constexpr int AVAIL = SCRATCH - (TI + 1) * BM;
     constexpr int RR = (MODE == MODE_TCONV3 || PW % 4 != 0) ? 0 : (AVAIL >= NWV * 32 * TP) ? 32 : (AVAIL >= NWV * 16 * TP) ? 16 : (AVAIL >= NWV * 8 * TP) ? 8 : 0;
@@ -245,7 +247,7 @@ __device__ __forceinline__ void modconv_finish(const ide3d_modconv_params& p, fl
             const int c4 = lane % (TW / 4), row0 = lane / (TW / 4);
             const int pix = pbase + (c4 * 4) / QX, ti = pix / (PH * PW), rem = pix % (PH * PW);
             const int n = n0 + ti, gy = y0 + rem / PW, gx = x0 + rem % PW;
-            const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + qy : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
+            const int oy = (MODE == MODE_TCONV3A) ? 2 * gy + (ROWPAR >= 0 ? ROWPAR : qy) : gy, ox = (MODE == MODE_TCONV3A) ? 2 * gx : gx;
             const bool px_ok = n < p.n && oy < g.oh && ox < g.ow, full = ox + 3 < g.ow;
             const int64_t pofs = (int64_t)oy * pitch + ox, nofs = (int64_t)oy * g.ow + ox;
             f32x4u nz = {0.f, 0.f, 0.f, 0.f};
@@ -588,14 +590,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // NWV: 4 waves (2 x 2), or 8 waves (2 x 4, two per SIMD) with time-shifted roles: waves 0-3 stage the patch and start multiplying at
 // once, waves 4-7 first issue the weight DMA of the next stage (the issuing wave is stuck for most of the transfer, ~19 B/clk/CU)
 // and multiply afterwards: the matrix pipe of every SIMD always has one of the two to take instructions from.
-template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV_ = 4>
+// PAIR (all-class transposed form only): the workgroup computes the two column classes of ONE output-row parity (see modconv_split_pair_kernel)
+template <int MODE, int BIG, int PH, int PARTS, int WBUF = 2, int NWV_ = 4, int PAIR = 0>
 struct SpCfg {
     static_assert(MODE == MODE_CONV3 || MODE == MODE_TCONV3A, "split-bf16 loop: 3x3 and all-class transposed 3x3 only");
     static_assert(BIG == 1 || BIG == 2, "64- or 128-row blocks");
     static_assert(NWV_ == 4 || NWV_ == 8, "4 or 8 waves");
     static constexpr int PW = 16, NWV = NWV_, NT = 64 * NWV;
     static constexpr int BN = PH * PW;
-    static constexpr int NCLS = (MODE == MODE_TCONV3A) ? 4 : 1;
+    static_assert(!PAIR || MODE == MODE_TCONV3A, "row-parity pairs exist in the transposed form only");
+    static constexpr int NCLS = (MODE == MODE_TCONV3A) ? (PAIR ? 2 : 4) : 1;
     // wave grid WM x WN over (rows, pixels).  64-row blocks on 32 x 16 pixels (round 4): 1 x 8, i.e. 64 x 64 outputs per wave like the
     // 128-row forms — the 2 x 4 grid of the 16 x 16-pixel form gives 32 x 64 per wave: 3 operand reads per 2 MFMAs instead of 4 per 4
     static constexpr int BM = (BIG == 1) ? 128 : 64;
@@ -605,7 +609,12 @@ struct SpCfg {
     static_assert(NTW >= 1 && NTW * 32 * WN == BN, "pixel tile must split into 32-pixel MFMA tiles per wave");
     static constexpr int NLOAD = 4;                                  // waves that stage (patch: waves 0-3; weights: the last four)
     static constexpr int KC = 16;
-    static constexpr int HP = PH + 2, HW = PW + 2, NSLOT = HP * HW;
+    // patch with halo: the transposed taps read offsets 0 and 1 only (input i - 1 and i), so their patch has ONE halo row / column
+#ifndef IDE3D_TA_HALO
+#define IDE3D_TA_HALO 1
+#endif
+    static constexpr int HALO = (MODE == MODE_TCONV3A) ? IDE3D_TA_HALO : 2;
+    static constexpr int HP = PH + HALO, HW = PW + HALO, NSLOT = HP * HW;
     static constexpr int NS = PARTS * (PARTS + 1) / 2;               // products per k step
     static constexpr int W_UNITS = 3 * PARTS * 2 * BM;               // 16-byte units per weight stage (one kernel row)
     static constexpr int X_UNITS = PARTS * 2 * NSLOT;                // per patch buffer
@@ -726,12 +735,18 @@ template <int PENDING>
 __device__ __forceinline__ void lds_wait128(u32x4& first) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(first) : "n"(PENDING)); }
 __device__ __forceinline__ void lds_pin128(u32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16, int TEAMS = 1>
+// PAR (all-class transposed form): -1 = all four output classes, three stages (kernel rows) per chunk; 0 / 1 = the two column classes of the even /
+// odd output rows only: kernel rows {0, 2} / {1} — out[2 i + ky] += x[i] w[ky] — i.e. two stages / one stage per chunk on twice the positions
+template <int MODE, int BIG, int PH, int PARTS, int WBUF, int NWV, int F16, int TEAMS = 1, int PAR = -1>
 __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p, const u32x4* __restrict__ wp, float* __restrict__ partial,
                                                    const ConvGeom& g, unsigned char* smem, int mb, int tl, int grp, int split, int tiles_x,
                                                    const float* __restrict__ row_unscale, float* wg_scratch = nullptr) {
-    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV>;
+    using K = SpCfg<MODE, BIG, PH, PARTS, WBUF, NWV, (PAR >= 0)>;
     static_assert(!F16 || PARTS == 2, "f16x3 = two fp16 pieces per operand");
+    static_assert(PAR < 0 || (MODE == MODE_TCONV3A && WBUF == 2 && TEAMS == 1), "row-parity pairs: transposed form, two weight buffers, one team");
+    // stages (kernel rows) of a chunk, in order
+    constexpr int NST = (PAR < 0) ? 3 : (PAR == 0 ? 2 : 1);
+    auto kys = [](int i) constexpr { return (PAR < 0) ? i : (PAR == 0 ? 2 * i : 1); };
     static_assert(TEAMS == 1 || (TEAMS == 2 && NWV == 4), "two teams of four waves, or one team");
     constexpr int PW = K::PW;
     // TEAMS = 2: two 4-wave teams in one 8-wave workgroup, each with its own tile (adjacent output-channel blocks of the same pixels, so
@@ -871,7 +886,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
     if (c_begin < c_end) {
-        if (WBUF == 2) { fetch_weights(c_begin * 3, 0); if (NWV == 8) fetch_weights(c_begin * 3, 0, true); }
+        if (WBUF == 2) { fetch_weights(c_begin * 3 + kys(0), 0); if (NWV == 8) fetch_weights(c_begin * 3 + kys(0), 0, true); }
         fetch_patch(c_begin);
         commit_patch(0);
     }
@@ -885,17 +900,19 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     for (int c = c_begin; c < c_end; ++c) {
         const int xbuf = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
-        static_for<3>([&](auto kyy) {
-            constexpr int KY = decltype(kyy)::value;
+        static_for<NST>([&](auto sii) {
+            constexpr int SI = decltype(sii)::value, KY = kys(SI);
+            constexpr bool LAST = (SI == NST - 1), MID = (SI == (NST == 3 ? 1 : 0));          // MID: the stage behind which the next chunk's patch is loaded
+            const int next_stage = LAST ? (c + 1) * 3 + kys(0) : c * 3 + kys(LAST ? 0 : SI + 1);
             IDE3D_MC_TS(0)
             if constexpr (WBUF == 2) {
-                if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1);
-                if (KY == 1 && more) fetch_patch(c + 1);
+                if (!LAST || more) fetch_weights(next_stage, wbuf ^ 1);
+                if (MID && more) fetch_patch(c + 1);
             } else {
                 // one weight buffer: this stage's slab is fetched now (everybody left the previous stage at the barrier below); the
                 // other workgroup of the CU multiplies meanwhile
                 fetch_weights(c * 3 + KY, 0);
-                if (KY == 1 && more) fetch_patch(c + 1);
+                if (MID && more) fetch_patch(c + 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
@@ -944,7 +961,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             };
             static_for<AHEAD>([&](auto ss) { issue(ss); });
             static_for<NGRP>([&](auto ss) {
-                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, QC = tap_class<MODE>(KY * 3 + KX);
+                constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, QC = (PAR >= 0) ? (KX & 1) : tap_class<MODE>(KY * 3 + KX);
                 constexpr int BS = B_REUSE ? (KX == 2 ? 1 : 0) : B;
                 if constexpr (S + AHEAD < NGRP) issue(std::integral_constant<int, S + AHEAD>{});
                 // reads issued after group S's own: those of the next min(AHEAD, groups left) groups
@@ -970,8 +987,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
                     }
             });
             IDE3D_MC_TS(2)
-            if (KY == 2 && more) commit_patch(xbuf ^ 1);
-            if constexpr (WBUF == 2 && NWV == 8) { if (KY < 2 || more) fetch_weights(c * 3 + KY + 1, wbuf ^ 1, true); }
+            if (LAST && more) commit_patch(xbuf ^ 1);
+            if constexpr (WBUF == 2 && NWV == 8) { if (!LAST || more) fetch_weights(next_stage, wbuf ^ 1, true); }
             IDE3D_MC_TS(3)
             if (WBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             IDE3D_MC_TS(4)
@@ -983,7 +1000,7 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
 #ifdef IDE3D_MC_TRACE
     const unsigned long long mc_t1 = __builtin_readcyclecounter();
 #endif
-    modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp,
+    modconv_finish<MODE, 1, PH, PW, K::NWV, K::NCLS, K::MTW, K::NTW, K::BM, K::LDS_BYTES / 4, PAR>(p, partial, g, acc, reinterpret_cast<float*>(smem), mb, n0, y0, x0, split, 0, wm, wn, lp,
                                                                                                 F16 ? row_unscale : nullptr, xus, (TEAMS == 2) ? tid : -1, wg_scratch);
 #ifdef IDE3D_MC_TRACE
     if (blockIdx.x == 100 && (threadIdx.x == 0 || threadIdx.x == 256)) {          // wave 0 (and wave 4 of an 8-wave workgroup, at [16..])
@@ -1562,6 +1579,34 @@ modconv_split_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float
     modconv_split_tile<MODE, BIG, PH, PARTS, WBUF, NWV, F16>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
 }
 
+// Row-parity pairs of the all-class transposed 3x3 convolution (round 5).  out[2 i + ky] += x[i] w[ky]: the even output rows take kernel rows 0 and 2,
+// the odd ones kernel row 1, so a workgroup that owns ONE row parity holds two accumulator sets (the column classes) instead of four and takes
+// twice the positions into the same registers: 16 x 16 positions x 128 rows (32 x 16 x 64 rows), 64 x 64 outputs per wave and class — a stage
+// (one kernel row = one 36 KB weight slab, one barrier) carries 72 MFMAs per wave like the stride-1 form, not 36.  The even-row workgroups run
+// two stages per chunk, the odd-row ones one: the first half of the grid is the even rows (dispatched first), the odd rows fill in behind
+// them, so the form pays where the launch is several rounds of one workgroup per CU.  Strip plans only (h x w grid; the last output row and
+// column come from tconv_strip_kernel).  Every accumulator sees the same products in the same order as in the all-class form: bit-equal results.
+// Measured (eager launch incl. the strip kernels, bf16x6, batch 4): 256 -> 128 in@128 243-251 -> 215-228 us; f16x3 152 -> 152.  The 64-row form
+// (32 x 16 positions) is SLOWER than the all-class 16 x 16 form (128 -> 64 in@256: 253 -> 291 us) and is only reachable with IDE3D_MODCONV_PAIR=2;
+// two launches (even rows, then odd rows) instead of one: no difference (the scalar spills of the two-path kernel do not matter).
+template <int BIG, int PH, int PARTS, int F16 = 0>
+__global__ void __launch_bounds__(512, 2)
+modconv_split_pair_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, float* __restrict__ partial, ConvGeom g, const float* __restrict__ row_unscale) {
+    using K = SpCfg<MODE_TCONV3A, BIG, PH, PARTS, 2, 8, 1>;
+    if constexpr (kSpExclusive) asm volatile("" ::: "v255");
+    __shared__ __attribute__((aligned(16))) unsigned char sp_smem[K::LDS_BYTES];
+    const int half_grid = (int)(gridDim.x >> 1);
+    const int par = __builtin_amdgcn_readfirstlane((int)blockIdx.x >= half_grid ? 1 : 0);
+    int bid = xcd_remap((int)blockIdx.x - par * half_grid, half_grid);
+    BlockId b;
+    b.mb = bid % g.mblocks; bid /= g.mblocks;
+    b.tile = bid % g.tile_base[4]; bid /= g.tile_base[4];
+    b.grp = bid % g.img_groups; bid /= g.img_groups;
+    b.split = bid;
+    if (par == 0) modconv_split_tile<MODE_TCONV3A, BIG, PH, PARTS, 2, 8, F16, 1, 0>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
+    else          modconv_split_tile<MODE_TCONV3A, BIG, PH, PARTS, 2, 8, F16, 1, 1>(p, wp, partial, g, sp_smem, b.mb, b.tile, b.grp, b.split, g.tiles_x[0], row_unscale);
+}
+
 // Two 4-wave teams per workgroup (exclusive residency without giving up the second wave per SIMD for the forms whose tile is too small
 // for eight waves: the 4 x 16-position transposed tiles of the 4^2 .. 32^2 layers).  Team t takes output-channel block 2 k + t of the same
 // (tile, image, K split): same geometry, same number of stages, so the workgroup barriers inside the tile code line up; each team has its
@@ -1685,6 +1730,7 @@ struct ConvPlan {
     int bm, kc, taps, mblocks, cchunks, oh, ow;
     int parts;                       // 0: fp32 MFMA loop; 2 / 3: split loop with that many pieces per operand
     int f16;                         // split loop on fp16 pieces (f16x3: parts == 2) instead of bf16
+    int pair;                        // all-class transposed conv, split loop: one output-row parity per workgroup (modconv_split_pair_kernel), grid doubled
     int strip;                       // all-class transposed conv on the h x w class grid; output row 2h and column 2w by tconv_strip_kernel
     int64_t strip_off, strip_floats; // packed strip weights [cin][6][cout_pad] inside the aux region (every all-class plan reserves them)
     int64_t packed_floats, aux_floats, partial_floats;      // aux: per-row scale + unscale of the f16x3 weights
@@ -1776,7 +1822,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.oh = transposed ? 2 * p.h + 1 : (pl.mode == MODE_CONV3S2) ? (p.h - 3) / 2 + 1 : p.h;
     pl.ow = transposed ? 2 * p.w_ + 1 : (pl.mode == MODE_CONV3S2) ? (p.w_ - 3) / 2 + 1 : p.w_;
     pl.packed_floats = (int64_t)pl.mblocks * pl.cchunks * pl.taps * pl.kc * pl.bm * (p.w_batch_stride ? p.n : 1);
-    pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0;
+    pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0; pl.pair = 0;
     int want_split = 0;                                         // split-K chosen together with the form (0 = by block count below)
     bool one_round = false;                                     // transposed 8-wave form chosen for whole rounds on the strip plan's grid: no split-K
     static const int split_min = getenv("IDE3D_MODCONV_SPLIT_MIN") ? atoi(getenv("IDE3D_MODCONV_SPLIT_MIN")) : 512;      // fewer workgroups than this: split-K
@@ -1861,6 +1907,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 // against 512 four-wave workgroups of 4 x 16; 512 -> 512 in@32 (64 rows): 149 -> 141 against 256 two-team workgroups
                 const bool strip_ok = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
                 const int64_t b8s = (int64_t)pl.mblocks * cdiv(p.h, 8) * cdiv(p.w_, 16) * p.n, b4s = (int64_t)pl.mblocks * cdiv(p.h, 4) * cdiv(p.w_, 16) * p.n;
+                const int64_t b16s = (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n;
                 auto rounds = [](int64_t blocks) { return (blocks + kNumCU - 1) / kNumCU; };
                 if (pl.big == 1) {
                     pl.tile = (b8 >= 2 * kNumCU) ? 6 : 4;
@@ -1868,6 +1915,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                     if (pl.tile == 4 && strip_ok && b8s >= kNumCU && rounds(b8s) * 200 <= rounds(b4s) * 115) { pl.tile = 6; one_round = true; }
                 }
                 else if (b16 >= 2 * kNumCU) pl.tile = 7;
+                // whole rounds of ONE 8-wave workgroup of 16 x 16 positions per CU on the strip grid (128 -> 64 in@256 at batch 1: 256 workgroups) against
+                // four-wave workgroups of 4 x 16 (a quarter of the work at ~1.15 x the time per unit; no team pairs with an odd block count)
+                else if (strip_ok && (pl.mblocks & 1) && b16s >= kNumCU && rounds(b16s) * 400 <= rounds(b4s) * 115 && !getenv("IDE3D_MODCONV_NO_R16")) { pl.tile = 7; one_round = true; }
                 else if (strip_ok && (pl.mblocks & 1) == 0 && b8s >= kNumCU && rounds(b8s) * 100 <= rounds(b4s / 2) * 105) { pl.tile = 6; one_round = true; }
                 else if (p.h <= 16 && p.w_ <= 16 && (pl.mblocks & 1)) pl.tile = 6;       // 4^2 .. 16^2 maps with an odd block count (no team pairs): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves alone on a CU: 115 / 47 / 31; two 4-wave teams: 92 / 45 / 24)
             }
@@ -1886,6 +1936,19 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         const int ph = (pl.tile == 4) ? 4 : (pl.tile == 0 || pl.tile == 6) ? 8 : (pl.tile == 12) ? 32 : 16;
         const int lds = 2 * 16 * (3 * pl.parts * 2 * pl.bm + pl.parts * 2 * (ph + 2) * 18);
         if (sp_maxlds && lds > sp_maxlds) pl.parts = 0;
+        // Row-parity pairs (modconv_split_pair_kernel): twice the positions per workgroup, 72 MFMAs per stage.  The even-row workgroups carry two
+        // stages per chunk, the odd-row ones one, so the form needs at least one whole round of even-row workgroups (one per CU) for the odd rows
+        // to fill in behind: 256 -> 128 in@128 at batch 4; 512 -> 256 in@64 (128 per parity: 215 -> 237 us) keeps the 8 x 16 form; 128-row blocks
+        // only (see the kernel).  IDE3D_MODCONV_PAIR (read per call: the tests flip it): 0 = never, 2 = wherever the form exists.
+        if (pl.parts && pl.mode == MODE_TCONV3A && kSpExclusive && !sp_rows && !sp_maxlds) {
+            const char* pe = getenv("IDE3D_MODCONV_PAIR");
+            const int pair_knob = pe ? atoi(pe) : 1;
+            const bool plain = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP");
+            const int64_t per_parity = (int64_t)pl.mblocks * cdiv(p.h, pl.big == 1 ? 16 : 32) * cdiv(p.w_, 16) * p.n;
+            if (plain && pair_knob && (pair_knob == 2 || (pl.big == 1 && per_parity >= kNumCU && p.cin >= 64))) {
+                pl.pair = 1; pl.tile = (pl.big == 1) ? 7 : 12; one_round = true;
+            }
+        }
     }
     if (!pl.parts) pl.f16 = 0;
     if (pl.parts) {
@@ -1908,7 +1971,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
         const int64_t groups = cdiv(p.n, TIv[pl.tile]);
         auto splits = [&](int64_t tiles) { return (int64_t)pl.mblocks * tiles * groups < split_min && pl.cchunks >= 8; };
-        if (t_main < t_full && (one_round || (!splits(t_main) && !splits(t_full)))) {
+        if (pl.pair || (t_main < t_full && (one_round || (!splits(t_main) && !splits(t_full))))) {
             pl.strip = 1;
             for (int c = 0; c < 4; ++c) { gh[c] = p.h; gw[c] = p.w_; }
         }
@@ -1976,6 +2039,7 @@ static SpForm sp_form(const ConvPlan& pl) {
     static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
     static const bool no_teams = getenv("IDE3D_SP_NO_TEAMS") != nullptr, no8 = getenv("IDE3D_MODCONV_SP_W4") != nullptr;
     const bool conv3 = (pl.mode == MODE_CONV3);
+    if (pl.pair) return {8, false};
     // 64-row blocks, even block count: two teams per workgroup (128-row blocks: LDS does not fit twice in bf16x6, and in f16x3 the teams measured 233 vs 217 us at 512 -> 256 in@64)
     if (pl.tile == 4) return {4, !conv3 && pl.big == 2 && kSpExclusive && !no_teams && (pl.mblocks & 1) == 0};
     if (pl.tile == 0 || pl.tile == 6) return {(w8 & (conv3 ? 1 : 2)) ? 8 : 4, false};
@@ -1990,6 +2054,10 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     const u32x4* wu = reinterpret_cast<const u32x4*>(wp);
     const float* ru = F16 ? wp + pl.packed_floats + (int64_t)pl.mblocks * pl.bm : nullptr;       // [row scale | row unscale] behind the packed weights
     const SpForm form = sp_form(pl);
+    if (pl.pair) {
+        if constexpr (MODE == MODE_TCONV3A) IDE3D_EXCL_LAUNCH((modconv_split_pair_kernel<BIG, (BIG == 1 ? 16 : 32), PARTS, F16>), dim3(2 * nblocks), 512, 0, st, p, wu, partial, g, ru);
+        return;
+    }
     if (pl.tile == 4) {
         if constexpr (MODE == MODE_TCONV3A) {
             if constexpr (BIG == 2) {
@@ -2218,7 +2286,7 @@ extern "C" int ide3d_modconv_plan(const ide3d_modconv_params* pp, ide3d_modconv_
     int arith_eff = arith;
     if (arith_eff == 16 && !p.x_amax) arith_eff = 6;
     ConvPlan pl; plan_conv(p, pl, arith_eff);
-    const int64_t blocks = (int64_t)pl.g.mblocks * pl.g.tile_base[4] * pl.g.img_groups * pl.g.split_k;
+    const int64_t blocks = (int64_t)pl.g.mblocks * pl.g.tile_base[4] * pl.g.img_groups * pl.g.split_k * (pl.pair ? 2 : 1);
     out->tile_h = PHv[pl.tile]; out->tile_w = PWv[pl.tile]; out->images_per_tile = TIv[pl.tile];
     out->rows = pl.bm; out->parts = pl.parts; out->f16 = pl.f16; out->split_k = pl.g.split_k; out->strip = pl.strip;
     out->transposed_all_class = (pl.mode == MODE_TCONV3A);

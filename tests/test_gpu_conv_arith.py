@@ -648,6 +648,43 @@ def test_transposed_strip_plan_equals_full_grid(gpu_device, shape, name):
     assert torch.equal(am_strip.amax(dim=1), y_strip.abs().amax(dim=(1, 2, 3))), 'y_amax must cover the strip'
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 128, 20, 24), (3, 80, 130, 16, 16), (3, 64, 384, 61, 70), (1, 48, 64, 33, 17), (4, 256, 128, 128, 128)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('name', ['bf16x6', 'bf16x3', 'f16x3'])
+def test_row_parity_pairs_equal_the_all_class_form(gpu_device, shape, name):
+    """Round 5: `modconv_split_pair_kernel` (one output-row parity per workgroup: kernel rows {0, 2} / {1}, two accumulator sets on twice the
+    positions) against the all-class form of the same layer (IDE3D_MODCONV_PAIR=0).  Every accumulator sees the same products in the same order,
+    so wherever the two plans agree in blocking, split-K and strip the results (and `y_amax`) are BIT-EQUAL; otherwise both are within the
+    arithmetic's tolerance of float64.  Ragged maps (tiles hanging over both edges), 64- and 128-row blocks, 2 .. 16 K chunks."""
+    import os
+    from torch_utils import hip_plugin
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(n, cin, h, w_, generator=g).to(gpu_device); wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(gpu_device)
+    s = (torch.randn(n, cin, generator=g) + 1).to(gpu_device); d = (torch.rand(n, cout, generator=g) + 0.5).to(gpu_device)
+    xam = _finite_amax(x)
+    res = {}
+    try:
+        for knob in ('0', '2'):
+            os.environ['IDE3D_MODCONV_PAIR'] = knob
+            am = torch.zeros(n, 32 * 64, device=gpu_device)
+            y = _mc()(x, wt, s, d, None, 0.0, None, 1, 0.0, 1.0, -1.0, mode=2, arith=ARITH[name], x_amax=xam, y_amax=am, pad_rows=True)
+            pl = hip_plugin.modconv_plan(n, cin, cout, h, w_, mode=2, arith=ARITH[name], epilogue='plain', x_amax=True)
+            res[knob] = (y, am.amax(dim=1), pl)
+    finally:
+        os.environ.pop('IDE3D_MODCONV_PAIR', None)
+    (y0, a0, p0), (y2, a2, p2) = res['0'], res['2']
+    assert p2['workgroups'] % 2 == 0 and (p2['tile_h'], p2['tile_w']) == ((16, 16) if p2['rows'] == 128 else (32, 16)) and p2['strip'] == 1 and p2['split_k'] == 1, p2
+    assert (p0['tile_h'], p0['workgroups']) != (p2['tile_h'], p2['workgroups']), 'IDE3D_MODCONV_PAIR=0 must give the all-class form'
+    ref = torch.nn.functional.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2) * d.double()[:, :, None, None]
+    scale = float(ref.abs().max())
+    for y in (y0, y2):
+        assert float((y.double() - ref).abs().max()) / scale < TOL[name]
+    assert torch.equal(a2, y2.abs().amax(dim=(1, 2, 3)))
+    if (p0['rows'], p0['strip'], p0['split_k'], p0['parts'], p0['f16']) == (p2['rows'], p2['strip'], p2['split_k'], p2['parts'], p2['f16']):
+        assert torch.equal(y0, y2) and torch.equal(a0, a2), 'same products in the same order: the pair form must reproduce the all-class form bit for bit'
+
+
 def test_every_matrix_loop_is_alone_on_its_cu_on_this_device(gpu_device):
     """Exclusive residency is checked where the kernels RUN, not assumed from the source: every launch of a kernel with an
     LDS-fed bf16 / fp16 matrix loop first asks the runtime how many of its workgroups fit one CU of this device

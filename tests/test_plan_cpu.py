@@ -42,7 +42,7 @@ def test_64_row_3x3_layer_uses_the_32x16_tile():
 
 
 @pytest.mark.parametrize('cin,cout,res,tile,rows,wgs', [
-    (512, 512, 32, (8, 16), 64, 256), (512, 256, 64, (8, 16), 128, 256), (256, 128, 128, (8, 16), 128, 512), (128, 64, 256, (16, 16), 64, 1024),
+    (512, 512, 32, (8, 16), 64, 256), (512, 256, 64, (8, 16), 128, 256), (256, 128, 128, (16, 16), 128, 512), (128, 64, 256, (16, 16), 64, 1024),
     (32, 128, 128, (8, 16), 128, 512)])
 def test_transposed_layers_run_the_strip_plan_at_whole_rounds(cin, cout, res, tile, rows, wgs):
     p = plan(cin=cin, cout=cout, h=res, w=res, mode=2, epilogue='plain')
@@ -51,6 +51,31 @@ def test_transposed_layers_run_the_strip_plan_at_whole_rounds(cin, cout, res, ti
     # an epilogue with noise / bias / activation belongs to the main kernel: no strip kernel could finish it
     q = plan(cin=cin, cout=cout, h=res, w=res, mode=2, epilogue='conv')
     assert q['strip'] == 0
+
+
+def test_row_parity_pairs_where_the_even_rows_fill_a_round(monkeypatch):
+    """Round 5: one output-row parity per workgroup (modconv_split_pair_kernel: 16 x 16 positions x 128 rows, twice the workgroups of the
+    same position grid) where >= 256 even-row workgroups exist; IDE3D_MODCONV_PAIR=0 restores the all-class 8 x 16 form, =2 forces the
+    form wherever it exists (the GPU tests compare the two bit for bit)."""
+    args = dict(cin=256, cout=128, h=128, w=128, mode=2, epilogue='plain')
+    pair = plan(**args)
+    assert (pair['tile_h'], pair['tile_w'], pair['rows'], pair['waves'], pair['workgroups'], pair['strip'], pair['split_k']) == (16, 16, 128, 8, 512, 1, 1)
+    assert plan(**dict(args, epilogue='conv'))['tile_h'] != 16                # the pairs need the strip plan, i.e. the plain epilogue
+    assert plan(**dict(args, n=1))['tile_h'] == 8                             # 64 even-row workgroups: no round to fill
+    assert plan(cin=512, cout=256, h=64, w=64, mode=2, epilogue='plain')['tile_h'] == 8       # 128 per parity
+    monkeypatch.setenv('IDE3D_MODCONV_PAIR', '0')
+    off = plan(**args)
+    assert (off['tile_h'], off['workgroups']) == (8, 512)
+    monkeypatch.setenv('IDE3D_MODCONV_PAIR', '2')
+    forced = plan(cin=64, cout=128, h=20, w=24, n=2, mode=2, epilogue='plain')
+    assert (forced['tile_h'], forced['rows'], forced['strip'], forced['split_k']) == (32, 64, 1, 1) and forced['workgroups'] == 2 * 2 * 1 * 2 * 2
+
+
+def test_batch_1_transposed_64_row_layer_runs_one_round_of_16x16():
+    """Round 5: 128 -> 64 in@256 at batch 1 = 256 eight-wave workgroups of 16 x 16 positions on the strip grid (was 1024 four-wave workgroups of
+    4 x 16: 92 -> 67 us)."""
+    p = plan(n=1, cin=128, cout=64, h=256, w=256, mode=2, epilogue='plain')
+    assert (p['kind'], p['tile_h'], p['tile_w'], p['rows'], p['waves'], p['workgroups'], p['strip'], p['split_k']) == ('split', 16, 16, 64, 8, 256, 1, 1)
 
 
 def test_low_resolution_transposed_layers_use_two_team_workgroups_with_split_k():
