@@ -354,6 +354,303 @@ upfirdn2d_tile_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int
     if (ep.y_amax) amax_raise_block(ep.y_amax, n, amax_t, reinterpret_cast<float*>(s_in));      // one read / atomic per tile
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 4x4 FIR at unit rate (the filter behind every transposed convolution of the generator), lean form (round 5)
+// ------------------------------------------------------------------------------------------------
+// The tile kernel above is VALU-issue bound on this shape, not HBM bound (round-5 reading of profiles/round5/fir_pmc.json: 832 vector
+// instructions per wave for 16 outputs per lane, of which 288 are the filter; SQ_INSTS_VALU x 4 cycles / SIMD = 73 % of the kernel's
+// cycles; more waves per SIMD, 7 instead of 5, changed nothing).  This kernel computes the same values in the same order (bit-equal) with the
+// bookkeeping taken out of the vector pipe:
+//   * every global access is `uniform base + 32-bit lane offset` (one v_mad + the instruction's own scalar base) instead of 64-bit pointer
+//     arithmetic per row (98 v_lshl_add_u64 + 56 v_mad_u64_u32 in the tile kernel);
+//   * out-of-image elements of the staged window are zeroed with ONE unsigned compare each on their true coordinates when the data arrives -
+//     no validity words carried across the loads (64-bit shifts / ors / selects, ~140 instructions);
+//   * the row loop has no per-row alignment tests: whether a lane's four outputs are a whole, aligned quad is decided once per lane (it is
+//     the same for its four rows), whether the epilogue has noise / bias / lrelu / clamp once per workgroup;
+//   * lrelu with 0 <= alpha <= 1 is max(v, v * alpha) (same value as the select for every input incl. -0 and NaN).
+// Conditions (else the tile kernel runs): fp32, w-contiguous, rows of x start 16-byte aligned and may be read up to round_up(in_w, 4)
+// (`x_row_floats`, see the tile kernel's fast staging), rows of y 16-byte aligned, out_w % 4 == 0, planes below 2^31 bytes, no skip operand.
+// Tile = 128 x 32 outputs per 256-thread workgroup (lane: 4 x 4), window 35 x 136 floats of LDS (the window starts on the 16-byte grid).
+__global__ void __launch_bounds__(256)
+fir44_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int tiles_x, int tiles_y) {
+    constexpr int TCX = 128, TCY = 32, LW = 136, LH = TCY + 3, NV = LW / 4, NLD = (LH * NV + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float s_in[LH * LW];
+    float g[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int fy = p.flip ? ky : 3 - ky, fx = p.flip ? kx : 3 - kx;
+            g[ky][kx] = p.f[fy * p.f_stride[0] + fx * p.f_stride[1]] * p.gain;
+        }
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx_i = bid % tiles_x; bid /= tiles_x;
+    const int ty_i = bid % tiles_y; bid /= tiles_y;
+    const int n = bid / p.c, c = bid % p.c;
+    const int in_x0 = tx_i * TCX - p.pad_x0, in_y0 = ty_i * TCY - p.pad_y0;
+    const int x_al = in_x0 & ~3, xoff = in_x0 - x_al;                 // LDS column 0 = the aligned column at or left of the window's first
+    const float* __restrict__ xp = (const float*)p.x + n * p.x_stride[0] + c * p.x_stride[1];       // (uniform: scalar base of every load)
+    const unsigned pitch = (unsigned)p.x_stride[2];
+    const int w4 = (p.in_w + 3) & ~3;
+    {
+        float4 v4[NLD];
+        int gy[NLD], gx[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = (int)threadIdx.x + k * 256;
+            const int ly = idx / NV, lv = idx - ly * NV;
+            gy[k] = in_y0 + ly; gx[k] = x_al + 4 * lv;
+            const unsigned cy_ = (unsigned)min(max(gy[k], 0), p.in_h - 1), cx_ = (unsigned)min(max(gx[k], 0), w4 - 4);
+            v4[k] = *reinterpret_cast<const float4*>(xp + (cy_ * pitch + cx_));
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = (int)threadIdx.x + k * 256;
+            if (idx < LH * NV) {
+                const bool rowok = (unsigned)gy[k] < (unsigned)p.in_h;
+                float4 w = v4[k];
+                w.x = (rowok && (unsigned)(gx[k] + 0) < (unsigned)p.in_w) ? w.x : 0.f;
+                w.y = (rowok && (unsigned)(gx[k] + 1) < (unsigned)p.in_w) ? w.y : 0.f;
+                w.z = (rowok && (unsigned)(gx[k] + 2) < (unsigned)p.in_w) ? w.z : 0.f;
+                w.w = (rowok && (unsigned)(gx[k] + 3) < (unsigned)p.in_w) ? w.w : 0.f;
+                *reinterpret_cast<float4*>(s_in + 4 * idx) = w;
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float win[7][7];
+    {
+        const float* wsrc = s_in + (ty * 4) * LW + tx * 4 + xoff;
+#pragma unroll
+        for (int wy = 0; wy < 7; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 7; ++wx) win[wy][wx] = wsrc[wy * LW + wx];
+    }
+    // epilogue switches, once per workgroup (scalar)
+    const bool has_noise = ep.noise != nullptr, act_on = ep.fused_act != 0;
+    const float nstr = ep.noise_strength;
+    const float bias = (act_on && ep.bias) ? ((const float*)ep.bias)[c] : 0.f;
+    const bool lrelu = act_on && ep.act == 3, lrelu_max = lrelu && ep.alpha >= 0.f && ep.alpha <= 1.f;
+    const float alpha = ep.alpha, again = act_on ? ep.act_gain : 1.f;
+    const bool clamp_on = act_on && ep.clamp >= 0.f;
+    const float cl = ep.clamp;
+    float* __restrict__ yp = (float*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
+    const unsigned ypitch = (unsigned)p.y_stride[2];
+    const int ox0 = tx_i * TCX + tx * 4, oy0 = ty_i * TCY + ty * 4;
+    const bool full = ox0 + 4 <= p.out_w;                            // (out_w % 4 == 0: a lane's quad is whole or absent)
+    float amax_t = 0.f;
+    if (full) {
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy) {
+            const int oy = oy0 + cy;
+            if (oy >= p.out_h) break;
+            float row[4];
+#pragma unroll
+            for (int cx = 0; cx < 4; ++cx) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) acc += win[cy + ky][cx + kx] * g[ky][kx];
+                row[cx] = acc;
+            }
+            if (has_noise) {
+                const float4 a = *reinterpret_cast<const float4*>(ep.noise + ((unsigned)oy * (unsigned)p.out_w + (unsigned)ox0));
+                row[0] += a.x * nstr; row[1] += a.y * nstr; row[2] += a.z * nstr; row[3] += a.w * nstr;
+            }
+            if (act_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = row[j] + bias;
+                    if (lrelu_max) v = fmaxf(v, v * alpha);
+                    else if (lrelu) v = (v > 0.f) ? v : v * alpha;
+                    v *= again;
+                    if (clamp_on) v = (v > cl) ? cl : ((v < -cl) ? -cl : v);
+                    row[j] = v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax_t = fmaxf(amax_t, fabsf(row[j]));
+            *reinterpret_cast<float4*>(yp + ((unsigned)oy * ypitch + (unsigned)ox0)) = make_float4(row[0], row[1], row[2], row[3]);
+        }
+    }
+    if (ep.y_amax) amax_raise_block(ep.y_amax, n, amax_t, s_in);
+}
+
+// the conditions of fir44_kernel (see there)
+static bool fir44_applies(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep) {
+    const bool off = getenv("IDE3D_FIR_NO_LEAN") != nullptr;      // read per call: tests/test_gpu_ops.py flips it inside one process
+    if (off || p.dtype != IDE3D_F32 || p.f_w != 4 || p.f_h != 4 || p.up_x != 1 || p.up_y != 1 || p.down_x != 1 || p.down_y != 1) return false;
+    if (p.x_stride[3] != 1 || p.y_stride[3] != 1 || ep.add || p.out_w <= 64 || (p.out_w & 3)) return false;
+    const int64_t pitch = p.x_stride[2], w4 = (p.in_w + 3) & ~3;
+    if ((pitch & 3) || pitch < w4 || w4 > (p.in_w > p.x_row_floats ? p.in_w : p.x_row_floats)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (p.x_stride[0] & 3) || (p.x_stride[1] & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.y) & 15) || (p.y_stride[0] & 3) || (p.y_stride[1] & 3) || (p.y_stride[2] & 3)) return false;
+    if (ep.noise && (reinterpret_cast<uintptr_t>(ep.noise) & 15)) return false;
+    if (pitch * p.in_h >= (1ll << 29) || p.y_stride[2] * (int64_t)p.out_h >= (1ll << 29) || (int64_t)p.out_w * p.out_h >= (1ll << 29)) return false;
+    if (p.x_stride[2] <= 0 || p.y_stride[2] <= 0) return false;
+    return true;
+}
+
+static int launch_fir44(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
+    const int tiles_x = cdiv(p.out_w, 128), tiles_y = cdiv(p.out_h, 32);
+    const int64_t nblocks = (int64_t)tiles_x * tiles_y * p.n * p.c;
+    if (nblocks > 0x7fffffff) { set_error("upfirdn2d: grid too large"); return IDE3D_EINVAL; }
+    hipLaunchKernelGGL(fir44_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, p, ep, tiles_x, tiles_y);
+    IDE3D_CHECK_LAUNCH("upfirdn2d (fir44)");
+    return IDE3D_OK;
+}
+
+// fp32 4x4 FIR with 2x zero-upsampling (the skip-image upsampler, upfirdn2d.upsample2d with the [1, 3, 3, 1] filter, optionally + the skip
+// operand), lean form: same polyphase arithmetic in the same order as upfirdn2d_tile_kernel<float, 2, 2, 1, 1, 4, 4, 2, 2> (bit-equal; that
+// kernel spends 386 vector instructions per wave on 64 multiply-adds per lane), bookkeeping as in fir44_kernel.  Tile = 64 x 16 cells
+// (128 x 32 outputs) per 256-thread workgroup, lane = 2 x 2 cells = 4 x 4 outputs from a 4 x 4 window.
+__global__ void __launch_bounds__(256)
+fir_up2_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int tiles_x, int tiles_y) {
+    using AX = Axis<2, 1, 4>;
+    constexpr int TCX = 64, TCY = 16, LW = 72, LH = TCY + 2, NV = LW / 4, NLD = (LH * NV + 255) / 256;
+    static_assert(AX::window(TCX) + 3 <= LW && AX::NT == 2 && AX::window(2) == 4, "window of the 4-tap polyphase filter");
+    __shared__ __attribute__((aligned(16))) float s_in[LH * LW];
+    float g[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int fy = p.flip ? ky : 3 - ky, fx = p.flip ? kx : 3 - kx;
+            g[ky][kx] = p.f[fy * p.f_stride[0] + fx * p.f_stride[1]] * p.gain;
+        }
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx_i = bid % tiles_x; bid /= tiles_x;
+    const int ty_i = bid % tiles_y; bid /= tiles_y;
+    const int n = bid / p.c, c = bid % p.c;
+    const int qx0 = floordiv(-p.pad_x0, 2) + tx_i * TCX, qy0 = floordiv(-p.pad_y0, 2) + ty_i * TCY;      // cell = input coordinate of LDS element (0, 0)
+    const int x_al = qx0 & ~3, xoff = qx0 - x_al;
+    const float* __restrict__ xp = (const float*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
+    const unsigned pitch = (unsigned)p.x_stride[2];
+    const int w4 = (p.in_w + 3) & ~3;
+    {
+        float4 v4[NLD];
+        int gy[NLD], gx[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = (int)threadIdx.x + k * 256;
+            const int ly = idx / NV, lv = idx - ly * NV;
+            gy[k] = qy0 + ly; gx[k] = x_al + 4 * lv;
+            const unsigned cy_ = (unsigned)min(max(gy[k], 0), p.in_h - 1), cx_ = (unsigned)min(max(gx[k], 0), w4 - 4);
+            v4[k] = *reinterpret_cast<const float4*>(xp + (cy_ * pitch + cx_));
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = (int)threadIdx.x + k * 256;
+            if (idx < LH * NV) {
+                const bool rowok = (unsigned)gy[k] < (unsigned)p.in_h;
+                float4 w = v4[k];
+                w.x = (rowok && (unsigned)(gx[k] + 0) < (unsigned)p.in_w) ? w.x : 0.f;
+                w.y = (rowok && (unsigned)(gx[k] + 1) < (unsigned)p.in_w) ? w.y : 0.f;
+                w.z = (rowok && (unsigned)(gx[k] + 2) < (unsigned)p.in_w) ? w.z : 0.f;
+                w.w = (rowok && (unsigned)(gx[k] + 3) < (unsigned)p.in_w) ? w.w : 0.f;
+                *reinterpret_cast<float4*>(s_in + 4 * idx) = w;
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float win[4][4];
+    {
+        const float* wsrc = s_in + (ty * 2) * LW + tx * 2 + xoff;
+#pragma unroll
+        for (int wy = 0; wy < 4; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 4; ++wx) win[wy][wx] = wsrc[wy * LW + wx];
+    }
+    const bool has_add = ep.add != nullptr, has_noise = ep.noise != nullptr, act_on = ep.fused_act != 0;
+    const float nstr = ep.noise_strength;
+    const float bias = (act_on && ep.bias) ? ((const float*)ep.bias)[c] : 0.f;
+    const bool lrelu = act_on && ep.act == 3, lrelu_max = lrelu && ep.alpha >= 0.f && ep.alpha <= 1.f;
+    const float alpha = ep.alpha, again = act_on ? ep.act_gain : 1.f;
+    const bool clamp_on = act_on && ep.clamp >= 0.f;
+    const float cl = ep.clamp;
+    float* __restrict__ yp = (float*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
+    const float* __restrict__ ap = has_add ? (const float*)ep.add + n * ep.add_stride[0] + c * ep.add_stride[1] : nullptr;
+    const unsigned ypitch = (unsigned)p.y_stride[2], apitch = (unsigned)ep.add_stride[2];
+    const int ox0 = (qx0 + tx * 2) * 2 + p.pad_x0;                  // first of this lane's four outputs (a multiple of 4: checked on the host)
+    const bool full = ox0 >= 0 && ox0 + 4 <= p.out_w;
+    float amax_t = 0.f;
+    if (full) {
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry) {
+                const int oy = (qy0 + ty * 2 + cy) * 2 + ry + p.pad_y0;
+                if (oy < 0 || oy >= p.out_h) continue;
+                float row[4];
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+                    for (int rx = 0; rx < 2; ++rx) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ty_ = 0; ty_ < 2; ++ty_)
+#pragma unroll
+                            for (int tx_ = 0; tx_ < 2; ++tx_)
+                                acc += win[cy + AX::off(ry) + ty_][cx + AX::off(rx) + tx_] * g[AX::first(ry) + ty_ * 2][AX::first(rx) + tx_ * 2];
+                        row[cx * 2 + rx] = acc;
+                    }
+                if (has_add) {
+                    const float4 a = *reinterpret_cast<const float4*>(ap + ((unsigned)oy * apitch + (unsigned)ox0));
+                    row[0] += a.x; row[1] += a.y; row[2] += a.z; row[3] += a.w;
+                }
+                if (has_noise) {
+                    const float4 a = *reinterpret_cast<const float4*>(ep.noise + ((unsigned)oy * (unsigned)p.out_w + (unsigned)ox0));
+                    row[0] += a.x * nstr; row[1] += a.y * nstr; row[2] += a.z * nstr; row[3] += a.w * nstr;
+                }
+                if (act_on) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = row[j] + bias;
+                        if (lrelu_max) v = fmaxf(v, v * alpha);
+                        else if (lrelu) v = (v > 0.f) ? v : v * alpha;
+                        v *= again;
+                        if (clamp_on) v = (v > cl) ? cl : ((v < -cl) ? -cl : v);
+                        row[j] = v;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax_t = fmaxf(amax_t, fabsf(row[j]));
+                *reinterpret_cast<float4*>(yp + ((unsigned)oy * ypitch + (unsigned)ox0)) = make_float4(row[0], row[1], row[2], row[3]);
+            }
+    }
+    if (ep.y_amax) amax_raise_block(ep.y_amax, n, amax_t, s_in);
+}
+
+static bool fir_up2_applies(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep) {
+    const bool off = getenv("IDE3D_FIR_NO_LEAN") != nullptr;      // read per call: tests/test_gpu_ops.py flips it inside one process
+    if (off || p.dtype != IDE3D_F32 || p.f_w != 4 || p.f_h != 4 || p.up_x != 2 || p.up_y != 2 || p.down_x != 1 || p.down_y != 1) return false;
+    if (p.x_stride[3] != 1 || p.y_stride[3] != 1 || (p.out_w & 3) || (p.in_w & 3)) return false;
+    // a lane's four outputs start at ((floor(-pad_x0 / 2) + 2 k) * 2 + pad_x0: a multiple of 4 for even pads (upsample2d: 2), never for odd ones
+    if (p.pad_x0 & 1) return false;
+    const int64_t pitch = p.x_stride[2];
+    if ((pitch & 3) || pitch < p.in_w || pitch <= 0 || p.y_stride[2] <= 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (p.x_stride[0] & 3) || (p.x_stride[1] & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.y) & 15) || (p.y_stride[0] & 3) || (p.y_stride[1] & 3) || (p.y_stride[2] & 3)) return false;
+    if (ep.add && (ep.add_stride[3] != 1 || (reinterpret_cast<uintptr_t>(ep.add) & 15) || (ep.add_stride[0] & 3) || (ep.add_stride[1] & 3) || (ep.add_stride[2] & 3) ||
+                   ep.add_stride[2] <= 0 || ep.add_stride[2] * (int64_t)p.out_h >= (1ll << 29))) return false;
+    if (ep.noise && (reinterpret_cast<uintptr_t>(ep.noise) & 15)) return false;
+    if (pitch * p.in_h >= (1ll << 29) || p.y_stride[2] * (int64_t)p.out_h >= (1ll << 29) || (int64_t)p.out_w * p.out_h >= (1ll << 29)) return false;
+    return true;
+}
+
+static int launch_fir_up2(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
+    auto cells = [](int out, int pad0) { return floordiv(out - 1 - pad0, 2) - floordiv(-pad0, 2) + 1; };
+    const int tiles_x = cdiv(cells(p.out_w, p.pad_x0), 64), tiles_y = cdiv(cells(p.out_h, p.pad_y0), 16);
+    const int64_t nblocks = (int64_t)tiles_x * tiles_y * p.n * p.c;
+    if (nblocks > 0x7fffffff) { set_error("upfirdn2d: grid too large"); return IDE3D_EINVAL; }
+    hipLaunchKernelGGL(fir_up2_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, p, ep, tiles_x, tiles_y);
+    IDE3D_CHECK_LAUNCH("upfirdn2d (fir_up2)");
+    return IDE3D_OK;
+}
+
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int CX, int CY>
 static int launch_tile(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
     constexpr int TCX = 32 * CX, TCY = 8 * CY;
@@ -392,10 +689,13 @@ static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilo
                 // 4 output rows per thread: 7 window rows serve 4 rows (halo 9 % instead of 19 %); narrow images get a
                 // 64-wide tile so that lanes are not wasted on columns that do not exist
                 if (p.out_w <= 64) return launch_tile<T, 1, 1, 1, 1, 4, 4, 2, 4>(p, ep, st);
+                if constexpr (std::is_same<T, float>::value) { if (fir44_applies(p, ep)) return launch_fir44(p, ep, st); }
                 return launch_tile<T, 1, 1, 1, 1, 4, 4, 4, 4>(p, ep, st);
             }
-            if (p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1)
+            if (p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1) {
+                if constexpr (std::is_same<T, float>::value) { if (fir_up2_applies(p, ep)) return launch_fir_up2(p, ep, st); }
                 return launch_tile<T, 2, 2, 1, 1, 4, 4, 2, 2>(p, ep, st);
+            }
             if (p.up_x == 1 && p.up_y == 1 && p.down_x == 2 && p.down_y == 2)
                 return launch_tile<T, 1, 1, 2, 2, 4, 4, 4, 2>(p, ep, st);
         }

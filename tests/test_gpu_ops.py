@@ -692,6 +692,61 @@ def test_upfirdn2d_fused_epilogue(gpu_device):
             assert_close(got, ref.float(), rtol=1e-5, atol=1e-5, what=f'up2+add {shape}')
 
 
+def test_lean_fir_kernels_equal_the_tile_kernels_bit_for_bit(gpu_device):
+    """Round 5: `fir44_kernel` (fp32 4x4 FIR at unit rate behind every transposed convolution: padded 16-byte aligned rows, out_w % 4 == 0)
+    and `fir_up2_kernel` (the skip upsampler) compute the tile kernels' values in the tile kernels' order with the bookkeeping taken out
+    of the vector pipe.  IDE3D_FIR_NO_LEAN=1 (read per call) routes the same launch to the tile kernel: outputs and `y_amax` must be
+    bit-equal for every epilogue, both flips, ragged tiles on both edges; and within 1e-5 of the float64 definition."""
+    import os
+    from torch_utils import hip_plugin
+    from torch_utils.ops import upfirdn2d as up, bias_act
+    P = hip_plugin.Upfirdn2dPlugin
+    g = torch.Generator().manual_seed(77)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(gpu_device)
+    f4 = up.setup_filter([1, 3, 3, 1], device=gpu_device)
+    fa = (torch.tensor([[1., 2., 3., 4.], [0.5, 3., 3., 1.], [2., 3., 5., 1.], [1., 3., 3., 7.]]) / 40).to(gpu_device)     # asymmetric: catches a flipped tap
+
+    def both(fn):
+        try:
+            os.environ['IDE3D_FIR_NO_LEAN'] = '1'
+            ref = fn()
+        finally:
+            os.environ.pop('IDE3D_FIR_NO_LEAN', None)
+        return fn(), ref
+
+    checked = 0
+    for n, c, h, w in ((2, 6, 513, 513), (1, 5, 77, 201), (3, 7, 129, 129), (1, 2, 257, 133)):
+        x = torch.nn.functional.pad(rn(n, c, h, w), (0, (-w) % 4))[..., :w]              # rows padded to 16 bytes, like the transposed convolution writes them
+        nz, bb = rn(h - 1, w - 1), rn(c)
+        for f in (f4, fa):
+            for flip in (False, True):
+                for kw in ({}, dict(noise=nz, noise_strength=0.7, bias=bb, act=3, alpha=0.2, act_gain=math.sqrt(2), clamp=-1.0),
+                           dict(noise=nz, noise_strength=0.7, bias=bb, act=3, alpha=0.2, act_gain=math.sqrt(2), clamp=0.8),
+                           dict(bias=bb, act=1, alpha=0.0, act_gain=1.0, clamp=-1.0), dict(bias=bb, act=3, alpha=1.5, act_gain=1.0, clamp=-1.0)):
+                    def run():
+                        am = torch.zeros(n, hip_plugin.AMAX_FLOATS, device=gpu_device)
+                        return P.upfirdn2d_ex(x, f, 1, 1, 1, 1, 1, 1, 1, 1, flip, 4.0, y_amax=am, **kw), am.amax(dim=1)
+                    (y, am), (yr, amr) = both(run)
+                    assert torch.equal(y, yr) and torch.equal(am, amr), f'fir44 {(n, c, h, w)} flip {flip} {sorted(kw)}'
+                    assert torch.equal(am, y.abs().amax(dim=(1, 2, 3)))
+                    checked += 1
+        ref = up._upfirdn2d_ref(x.cpu().double(), f4.cpu(), padding=[1] * 4, gain=4)
+        ref = bias_act._bias_act_ref(ref + nz.cpu().double() * 0.7, bb.cpu().double(), act='lrelu', gain=math.sqrt(2))
+        got = P.upfirdn2d_ex(x, f4, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0, noise=nz, noise_strength=0.7, bias=bb, act=3, alpha=0.2, act_gain=math.sqrt(2), clamp=-1.0)
+        assert_close(got, ref.float(), rtol=1e-5, atol=1e-5, what=f'fir44 + epilogue {(n, c, h, w)}')
+    for n, c, h, w in ((2, 12, 128, 128), (1, 22, 256, 256), (3, 5, 8, 8), (2, 3, 20, 36), (1, 4, 64, 200)):
+        x, add, bb = rn(n, c, h, w), rn(n, c, 2 * h, 2 * w), rn(c)
+        for f in (f4, fa):
+            for flip in (False, True):
+                for kw in ({}, dict(add=add), dict(add=add, bias=bb, act=3, alpha=0.2, act_gain=1.3, clamp=0.9)):
+                    (y, yr) = both(lambda: P.upfirdn2d_ex(x, f, 2, 2, 1, 1, 2, 1, 2, 1, flip, 4.0, **kw))
+                    assert torch.equal(y, yr), f'fir_up2 {(n, c, h, w)} flip {flip} {sorted(kw)}'
+                    checked += 1
+        ref = up._upfirdn2d_ref(x.cpu().double(), f4.cpu(), up=2, padding=[2, 1, 2, 1], gain=4) + add.cpu().double()
+        assert_close(P.upfirdn2d_ex(x, f4, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0, add=add), ref.float(), rtol=1e-5, atol=1e-5, what=f'fir_up2 + add {(n, c, h, w)}')
+    assert checked == 4 * 2 * 2 * 5 + 5 * 2 * 2 * 3
+
+
 def test_modconv2d_packed_weight_cache_is_identity_safe(gpu_device):
     """The packed-weight workspace is reused only for the same tensor object at the same version: an in-place update, or a
     different weight that lands on a recycled address, must be re-packed."""
