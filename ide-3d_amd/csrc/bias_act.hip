@@ -120,6 +120,40 @@ bias_act_vec_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* _
     }
 }
 
+// Forward pass over whole bias planes (round 5).  The kernel above finds its bias with `(i / step_b) % size_b` on 64-bit indices: a
+// software division of ~100 vector instructions per 16 bytes (profiles/round5/kernel_pmc.json: 4811 vector instructions per wave, VALU busy
+// 64 % of the launch at [4, 64, 512, 512] - an element-wise kernel bound by its index arithmetic, not by HBM), and evaluates `yref / gain` for
+// every element although the forward pass has no yref.  Here a workgroup works inside ONE plane of step_b elements (NCHW: one channel of
+// one image), so the bias is a scalar found once per workgroup, the gradient operands do not exist (G = 0 at compile time) and the
+// addresses are 32-bit offsets from the plane's base.  Same operations in the same order per element: bit-equal to the kernel above.
+constexpr int BA_ITER = 4;                                   // vectors per lane
+template <class T, int A, int VEC>
+__global__ void __launch_bounds__(256)
+bias_act_plane_kernel(const T* __restrict__ x, const T* __restrict__ b, T* __restrict__ y, float alpha_f, float gain_f, float clamp_f,
+                      unsigned vec_per_plane, unsigned chunks, unsigned size_b) {
+    using M = typename Elem<T>::math_t;
+    using V = Vec<T, VEC>;
+    const M alpha = (M)alpha_f, gain = (M)gain_f, clamp = (M)clamp_f;
+    const unsigned plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;        // uniform
+    const M bv = b ? Elem<T>::ld(b + plane % size_b) : (M)0;
+    const V* __restrict__ xv = reinterpret_cast<const V*>(x) + (int64_t)plane * vec_per_plane;
+    V* __restrict__ yv = reinterpret_cast<V*>(y) + (int64_t)plane * vec_per_plane;
+    const unsigned i0 = chunk * (256u * BA_ITER) + threadIdx.x;
+    V vx[BA_ITER];
+#pragma unroll
+    for (int it = 0; it < BA_ITER; ++it) { const unsigned i = i0 + it * 256u; if (i < vec_per_plane) vx[it] = xv[i]; }
+#pragma unroll
+    for (int it = 0; it < BA_ITER; ++it) {
+        const unsigned i = i0 + it * 256u;
+        if (i >= vec_per_plane) break;
+        V vo;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            Elem<T>::st(&vo.v[k], bias_act_one<T, A>(Elem<T>::ld(&vx[it].v[k]), bv, (M)0, (M)0, (M)1, 0, alpha, gain, clamp));
+        yv[i] = vo;
+    }
+}
+
 // Scalar kernel for the tail elements and for unaligned bases.
 template <class T, int A>
 __global__ void __launch_bounds__(256)
@@ -147,6 +181,19 @@ static int launch_bias_act(const void* x, const void* b, const void* xref, const
     auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool can_vec = aligned(x) && aligned(xref) && aligned(yref) && aligned(dy) && aligned(y);
     int64_t nvec = can_vec ? size_x / VEC : 0;
+    // forward pass over whole planes: the bias is constant inside a plane of step_b elements, planes of >= 256 vectors
+    if (nvec > 0 && grad == 0 && !xref && !yref && !dy && !getenv("IDE3D_BIAS_ACT_NO_PLANES")) {
+        const int64_t plane = b ? step_b : size_x;
+        if (plane % VEC == 0 && size_x % plane == 0 && plane / VEC >= 256 && plane / VEC < (1ll << 31) && size_b < (1ll << 31)) {
+            const int64_t vpp = plane / VEC, chunks = (vpp + 256 * BA_ITER - 1) / (256 * BA_ITER), blocks = (size_x / plane) * chunks;
+            if (blocks < (1ll << 31)) {
+                hipLaunchKernelGGL((bias_act_plane_kernel<T, A, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)b, (T*)y,
+                                   alpha, gain, clamp, (unsigned)vpp, (unsigned)chunks, (unsigned)size_b);
+                IDE3D_CHECK_LAUNCH("bias_act");
+                return IDE3D_OK;
+            }
+        }
+    }
     if (nvec > 0) {
         const int bias_per_vec = (step_b % VEC == 0) ? 1 : 0;
         int grid = stream_grid(nvec, 256);

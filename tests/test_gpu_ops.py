@@ -60,6 +60,31 @@ def test_bias_act_dtypes_layouts_and_tails(gpu_device, dtype, tol):
             assert_close(y.double(), ref, rtol=tol, atol=tol, what=f'{dtype} {shape} {act}')
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_bias_act_plane_kernel_equals_the_indexed_kernel(gpu_device, dtype):
+    """Round 5: the forward pass over whole bias planes (`bias_act_plane_kernel`: bias found once per workgroup, no 64-bit index division
+    per vector) against the indexed kernel (IDE3D_BIAS_ACT_NO_PLANES=1, read per call): bit-equal for every activation, with / without
+    bias and clamp, planes that are not a multiple of the workgroup's 1024 vectors, and the no-bias call (one plane = the tensor)."""
+    import os
+    from torch_utils.ops import bias_act
+    g = torch.Generator().manual_seed(4)
+    for shape in ((2, 6, 128, 128), (1, 3, 72, 100), (3, 4, 40, 40), (2, 2, 300, 52)):
+        x = (torch.randn(*shape, generator=g) * 2).to(dtype).to(gpu_device)
+        b = torch.randn(shape[1], generator=g).to(dtype).to(gpu_device)
+        for act in ('lrelu', 'linear', 'relu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish'):
+            for bias, clamp in ((b, None), (b, 0.7), (None, 0.7)):
+                try:
+                    os.environ['IDE3D_BIAS_ACT_NO_PLANES'] = '1'
+                    ref = bias_act.bias_act(x, bias, act=act, clamp=clamp)
+                finally:
+                    os.environ.pop('IDE3D_BIAS_ACT_NO_PLANES', None)
+                y = bias_act.bias_act(x, bias, act=act, clamp=clamp)
+                assert torch.equal(y.view(torch.int16 if dtype != torch.float32 else torch.int32), ref.view(torch.int16 if dtype != torch.float32 else torch.int32)), (shape, act, clamp)
+        y = bias_act.bias_act(x, b, act='lrelu')
+        want = oracle_ops.bias_act(x.cpu().double(), b.cpu().double(), act='lrelu')
+        assert_close(y.double(), want, rtol=2e-2 if dtype != torch.float32 else 2e-6, atol=2e-2 if dtype != torch.float32 else 2e-6, what=f'{dtype} {shape}')
+
+
 def test_bias_act_gradients(gpu_device):
     """First and second order gradients of the HIP op == autograd through the PyTorch definition."""
     from torch_utils.ops import bias_act
