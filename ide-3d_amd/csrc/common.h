@@ -35,21 +35,16 @@ void note_exclusive_violation(const char* kernel, int blocks_per_cu);
 void refuse_launch(const char* kernel);          // this thread's next IDE3D_CHECK_LAUNCH fails
 bool take_refused();
 int exclusive_violations();
+// The answer is cached per (kernel ADDRESS, device, threads, dynamic LDS): round 5 kept it in a function-template static, which every kernel
+// instantiation of the same SIGNATURE shared (all modconv_split_kernel<...> variants, all render_rays_kernel<...>): only the first-launched
+// variant was ever asked about.  core.hip owns the table.
+bool exclusive_checked(const void* kernel, int threads, size_t dyn_lds, const char* name);
 template <typename K>
 inline bool exclusive_on_this_device(K kernel, int threads, size_t dyn_lds, const char* name) {
-    static int occ[16] = {};                       // per instantiation (this is a template) and device: 0 = not asked yet
 #ifdef IDE3D_SP_SHARED_SIMD
     return true;                                   // A/B experiment build without the register claims
 #endif
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
-    if (occ[dev] == 0) {
-        int n = 0;
-        occ[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) == hipSuccess && n > 0) ? n : -1;
-        if (occ[dev] > 1) note_exclusive_violation(name, occ[dev]);
-    }
-    if (occ[dev] > 1) refuse_launch(name);
-    return occ[dev] <= 1;
+    return exclusive_checked(reinterpret_cast<const void*>(kernel), threads, dyn_lds, name);
 }
 #define IDE3D_EXCL_LAUNCH(KERNEL, GRID, THREADS, DYN_LDS, ST, ...) \
     do { if (ide3d::exclusive_on_this_device(KERNEL, (THREADS), (DYN_LDS), #KERNEL)) hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), DYN_LDS, ST, __VA_ARGS__); } while (0)

@@ -2,6 +2,9 @@
 #include "common.h"
 #include <string.h>
 #include <stdio.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace ide3d {
 
@@ -29,6 +32,29 @@ void refuse_launch(const char* kernel) {
               "(IDE3D_CONV_ARITH=fp32 selects the arithmetic that needs none)", kernel);
 }
 bool take_refused() { const bool r = g_refused; g_refused = false; return r; }
+
+// One occupancy query per (kernel address, device, workgroup size, dynamic LDS): a kernel whose LDS size varies per launch (raymarch) is
+// asked again for every size it is launched with.
+bool exclusive_checked(const void* kernel, int threads, size_t dyn_lds, const char* name) {
+    static std::mutex mu;
+    static std::map<std::tuple<const void*, int, int, size_t>, int> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    int occ;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_tuple(kernel, dev, threads, dyn_lds);
+        auto it = table.find(key);
+        if (it == table.end()) {
+            int n = 0;
+            occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) == hipSuccess && n > 0) ? n : -1;
+            table.emplace(key, occ);
+            if (occ > 1) note_exclusive_violation(name, occ);
+        } else occ = it->second;
+    }
+    if (occ > 1) refuse_launch(name);
+    return occ <= 1;
+}
 
 }  // namespace ide3d
 

@@ -44,6 +44,9 @@ _pools = {}                                  # (device index, stream handle) -> 
 STATS = collections.Counter()                # 'eager', 'capture', 'replay', 'ineligible:<why>' — read by tests and bench.py
 
 
+_PASS_ENV = ('IDE3D_NO_SKIP_MERGE', 'IDE3D_NO_STYLE_PREFETCH', 'IDE3D_NO_STYLE_BATCH', 'IDE3D_GATHER_PC', 'IDE3D_NO_LOWRES_GROUP', 'IDE3D_LOWRES_PERSISTENT')
+
+
 def _env_int(name, default):
     try:
         return int(os.environ.get(name, default))
@@ -210,7 +213,10 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
     sig = (kind, n, tuple(ws.shape[1:]), None if c is None else (tuple(c.shape), c.dtype), noise_mode, flags, bool(force_fp32), jit_kind, planes_key,
            render_params.get('fov'), steps, render_params.get('ray_start'), render_params.get('ray_end'),
            hip_plugin.conv_arithmetic(), networks.use_hip_modconv, torch.is_grad_enabled(), dev.index, hip_plugin._stream_handle(dev),
-           bool(getattr(module, 'style_prefetch', True)))
+           bool(getattr(module, 'style_prefetch', True)),
+           # what else selects the launch path per call: train / eval of the tree's blocks (`fused_modconv = not self.training`,
+           # networks.py) and the environment switches the pass reads while it runs
+           module.training, tuple(ch.training for ch in module.children()), tuple(os.environ.get(k) for k in _PASS_ENV))
 
     def current(stamp, requires_grad, hooked):
         """None when a replay is what the eager call would compute, else the reason it is not."""
@@ -223,17 +229,24 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
         return None
 
     ent = cache.entries.get(sig)
-    if ent is not None and ent.untouched():
+    # cheap rejections BEFORE the optimistic replay: with autograd the static input would join the caller's graph, and a hook on the root
+    # (the common place) needs no tree walk to be seen
+    replayable = not (torch.is_grad_enabled() and ws.requires_grad) and not module._forward_hooks and not module._forward_pre_hooks and not _global_hooks()
+    if ent is not None and replayable and ent.untouched():
         # Optimistic replay: the launch goes out first, the ~0.1 ms walk over the module tree (hooks, requires_grad, every parameter's
         # version and address) runs while the GPU works, and the copies are handed out only if the walk finds nothing.  In the drivers'
         # loops the host is on the critical path between a blocking `z.to(device)` and the first launch of the pass (gen_images.py:91-109).
         cache.entries.move_to_end(sig)
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        offset = gen.get_offset() if (ent.jitter is not None and not ent.jitter_given) else None
         out = _replay(ent, ws, c, ray_jitter, cached_planes)
         why = current(*tree_stamp(module))
         if why is None:
             STATS['replay'] += 1
             return out
         del out                      # a pure function of the static inputs was evaluated for nothing; the eager pass below is the answer
+        if offset is not None:
+            gen.set_offset(offset)   # the discarded replay's jitter draw is handed back: the eager pass below draws what a purely eager caller would
         STATS['replay_discarded'] += 1
 
     stamp, requires_grad, hooked = tree_stamp(module)
@@ -274,14 +287,15 @@ def _run_locked(cache, module, impl, ws, c, render_params, noise_mode, flags, fo
 
 
 def _replay(ent, ws, c, ray_jitter, cached_planes):
-    ent.ws.copy_(ws, non_blocking=True)
-    if ent.c is not None:
-        ent.c.copy_(c, non_blocking=True)
-    if ent.jitter is not None:
-        if ent.jitter_given:
-            ent.jitter.copy_(ray_jitter, non_blocking=True)
-        else:
-            ent.jitter.uniform_()
+    with torch.no_grad():            # the static inputs never join an autograd graph
+        ent.ws.copy_(ws, non_blocking=True)
+        if ent.c is not None:
+            ent.c.copy_(c, non_blocking=True)
+        if ent.jitter is not None:
+            if ent.jitter_given:
+                ent.jitter.copy_(ray_jitter, non_blocking=True)
+            else:
+                ent.jitter.uniform_()
     ent.graph.replay()
     return _fresh(ent.out, cached_planes)
 

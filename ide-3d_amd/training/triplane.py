@@ -533,14 +533,17 @@ class GraphedRenderer:
         # kernel's barrier counter) from workspaces owned by THIS object (hip_plugin.workspace_scope), not by a stream handle that
         # another graph or an eager caller may be handed as well; the replays reuse the copies packed during warm-up.
         scope = self._scope(device)
-        with torch.cuda.stream(stream), torch.no_grad(), scope, graph_cache.disabled():      # this object IS the capture: no automatic one inside it
-            for _ in range(warmup):
-                self._body()
-        torch.cuda.current_stream(device).wait_stream(stream)
-        torch.cuda.synchronize(device)
-        graph = torch.cuda.CUDAGraph()
-        with hip_plugin.capture_lock, torch.no_grad(), scope, torch.cuda.graph(graph, stream=stream):
-            self.out = self._body()
+        # the lock covers the warm-up too: all captures of a device share the 'graph capture' stream, and warm-up launches on it
+        # while another thread holds it in capture mode would be recorded into (or invalidate) that thread's graph
+        with hip_plugin.capture_lock:
+            with torch.cuda.stream(stream), torch.no_grad(), scope, graph_cache.disabled():      # this object IS the capture: no automatic one inside it
+                for _ in range(warmup):
+                    self._body()
+            torch.cuda.current_stream(device).wait_stream(stream)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), scope, torch.cuda.graph(graph, stream=stream):
+                self.out = self._body()
         self.graph = graph
         self._stream = stream
 

@@ -11,6 +11,7 @@ time (`kind='cubic'`, `wraps` periodic copies), one look-at camera per frame swe
 """
 
 import math
+import threading
 import weakref
 from typing import Iterable, Iterator, Sequence, Tuple
 
@@ -44,21 +45,37 @@ def interpolate_ws(ws_keyframes: np.ndarray, w_frames: int, kind: str = 'cubic',
     return interp(np.arange(k * w_frames) / w_frames).astype(np.float32)          # all frames in one evaluation (= the per-frame calls of gen_videos.py:127, bit for bit)
 
 
-_plane_buffers = weakref.WeakKeyDictionary()          # synthesis module -> the pair of buffers its static tri-planes are kept in
+_plane_pool = weakref.WeakKeyDictionary()          # synthesis module -> [[buffers, in_use], ...]: pairs of buffers static tri-planes are kept in
+_plane_pool_lock = threading.Lock()
 
 
-def _static_plane_buffers(synthesis, planes):
-    """The job's static tri-planes, copied into buffers that live as long as the generator: `G.synthesis` reads cached tri-planes in place and
-    keys its captured pass on their addresses (training/graph_cache.py), so the next video job of this generator replays the pass the previous
-    one captured instead of capturing its own (a capture costs ~3 passes + a device synchronisation: 10 % of a 120-frame job)."""
+def _checkout_plane_buffers(synthesis, planes):
+    """The job's static tri-planes, copied into buffers that outlive the job: `G.synthesis` reads cached tri-planes in place and keys its
+    captured pass on their addresses (training/graph_cache.py), so the next video job of this generator replays the pass the previous one
+    captured instead of capturing its own (a capture costs ~3 passes + a device synchronisation: 10 % of a 120-frame job).
+    A pair of buffers belongs to ONE live job at a time (two interleaved generators on one G shared a pair and the second
+    overwrote the planes the first was still rendering from): a job checks a pair out and `_release_plane_buffers` hands it back when the
+    generator finishes or is closed; a second live job of the same shape gets its own pair.  Returns (planes to render from, token)."""
     if not planes[0].is_cuda:
-        return planes
-    bufs = _plane_buffers.get(synthesis)
-    if bufs is None or any(b.shape != t.shape or b.stride() != t.stride() or b.device != t.device or b.dtype != t.dtype for b, t in zip(bufs, planes)):
-        bufs = _plane_buffers[synthesis] = tuple(torch.empty_like(t) for t in planes)          # empty_like keeps the channels-last strides
-    for b, t in zip(bufs, planes):
+        return planes, None
+    with _plane_pool_lock:
+        pool = _plane_pool.setdefault(synthesis, [])
+        ent = next((e for e in pool if not e[1] and all(b.shape == t.shape and b.stride() == t.stride() and b.device == t.device and b.dtype == t.dtype
+                                                        for b, t in zip(e[0], planes))), None)
+        if ent is None:
+            ent = [tuple(torch.empty_like(t) for t in planes), False]          # empty_like keeps the channels-last strides
+            pool.append(ent)
+            del pool[:-8]                                                      # bound: idle pairs of shapes no job uses any more
+        ent[1] = True
+    for b, t in zip(ent[0], planes):
         b.copy_(t)
-    return bufs
+    return ent[0], ent
+
+
+def _release_plane_buffers(token):
+    if token is not None:
+        with _plane_pool_lock:
+            token[1] = False
 
 
 def layout_u8(frames: torch.Tensor, grid_w: int, grid_h: int) -> torch.Tensor:
@@ -100,18 +117,21 @@ def gen_interp_frames(G, seeds: Sequence[int], shuffle_seed=None, w_frames: int 
                                            for yi in range(grid_h) for xi in range(grid_w)])).to(device)
     # one keyframe per cell: the spline through copies of one point is that point (up to interpolation round-off)
     static = cache_static_planes and num_keyframes == 1 and bool(torch.allclose(ws_frames, ws_frames[:, :1].expand_as(ws_frames), atol=1e-5))
-    planes = None
+    planes = token = None
     if static:
-        planes = _static_plane_buffers(G.synthesis, G.synthesis.planes(ws_frames[:, 0], noise_mode=noise_mode))
+        planes, token = _checkout_plane_buffers(G.synthesis, G.synthesis.planes(ws_frames[:, 0], noise_mode=noise_mode))
     palette = dr.palette_tensor(G.synthesis.seg_channels, device)
-    for frame_idx in range(total):
-        c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)
-        img, seg = G.synthesis(ws_frames[:, frame_idx], c=c, noise_mode=noise_mode, return_seg=True, cached_planes=planes, **synthesis_kwargs)
-        if image_mode == 'image_seg':
-            cell_frames = dr.frames_u8(img, seg, palette)
-        else:
-            cell_frames = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
-        yield layout_u8(cell_frames, grid_w, grid_h)
+    try:
+        for frame_idx in range(total):
+            c = sweep_pose(frame_idx, total, lookat, device=device).repeat(cells, 1)
+            img, seg = G.synthesis(ws_frames[:, frame_idx], c=c, noise_mode=noise_mode, return_seg=True, cached_planes=planes, **synthesis_kwargs)
+            if image_mode == 'image_seg':
+                cell_frames = dr.frames_u8(img, seg, palette)
+            else:
+                cell_frames = (img.float() * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            yield layout_u8(cell_frames, grid_w, grid_h)
+    finally:
+        _release_plane_buffers(token)          # also on generator.close() / garbage collection of an abandoned iterator
 
 
 # ---- dependency-free video sink --------------------------------------------------------------------------------------

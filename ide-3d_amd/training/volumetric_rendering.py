@@ -43,7 +43,10 @@ def device_const(values, dtype, device):
     the driver enqueues after it (the rest of the pose math, the synthesis pass) starts on an idle GPU.  The reference's
     create_cam2world_matrix does exactly that once per pose (volumetric_rendering.py:199); here the pose helpers never synchronise.
     Callers must not write to the returned tensor."""
-    key = (tuple(float(v) for v in values), dtype, str(device))
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:          # 'cuda' = whichever device is current NOW, not at the first call (ADVICE r5)
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (tuple(float(v) for v in values), dtype, device.type, device.index)
     t = _consts.get(key)
     if t is None:
         t = _consts[key] = torch.tensor(list(values), dtype=dtype, device=device)

@@ -97,7 +97,7 @@ def test_compact_line_of_a_full_size_gpu_record():
         'timing': {'blocks': 5, 'reported': 'median block', 'ms_per_step_min': big, 'ms_per_step_max': big},
         'conv_tflops': big, 'hip_graph': True, 'parity_ok': True,
         'parity': {'max_rel_err': {'img': 2.34e-06, 'seg': 2.84e-06}, 'tol_rel': 2e-05, 'vs': 'tests/golden/bench_parity.npz (CPU oracle)'},
-        'dropin_eager_b1': {'frames_per_s': big, 'ms_per_image': big, 'images': 24, 'what': 'x' * 90},
+        'dropin_b1': {'frames_per_s': big, 'ms_per_image': big, 'images': 24, 'what': 'x' * 90},
         'by_conv_arithmetic': {k: {'frames_per_s': big, 'parity_ok': True} for k in ('fp32', 'bf16x6', 'f16x3', 'bf16x3')},
         'roofline': {'kernel': 'triplane_sample_tile_pc_kernel', 'bound': 'hbm', 'achieved': big, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.5591,
                      'traffic': 258900000, 'traffic_measured_in_this_run': False, 'bytes_per_launch': 320864256, 'avg_launch_us': 71.83, 'timed_launches': 100},
