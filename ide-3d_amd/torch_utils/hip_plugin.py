@@ -21,7 +21,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 6
+_ABI_VERSION = 7
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -170,6 +170,27 @@ class _FoldJob(ctypes.Structure):
     ]
 
 
+LOWRES_MAX_LAYERS, LOWRES_MAX_HEADS = 8, 4          # IDE3D_LOWRES_MAX_*
+
+
+class _LowresLayer(ctypes.Structure):
+    _fields_ = [('weight', ctypes.c_void_p), ('styles', ctypes.c_void_p), ('dcoefs', ctypes.c_void_p), ('noise', ctypes.c_void_p), ('bias', ctypes.c_void_p),
+                ('act_gain', ctypes.c_float), ('clamp', ctypes.c_float), ('up', ctypes.c_int32), ('head', ctypes.c_int32),
+                ('weights_packed', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class _LowresHead(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('skip', ctypes.c_void_p), ('clamp', ctypes.c_float), ('O', ctypes.c_int32)]
+
+
+class _LowresParams(ctypes.Structure):
+    _fields_ = [('x0', ctypes.c_void_p), ('x0_batch_stride', ctypes.c_int64), ('fir', ctypes.c_void_p), ('x_out', ctypes.c_void_p),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_int64),
+                ('n', ctypes.c_int32), ('C', ctypes.c_int32), ('res0', ctypes.c_int32), ('nlayers', ctypes.c_int32), ('nheads', ctypes.c_int32),
+                ('arith', ctypes.c_int32), ('persistent', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('layers', _LowresLayer * LOWRES_MAX_LAYERS), ('heads', _LowresHead * LOWRES_MAX_HEADS)]
+
+
 class _MappingParams(ctypes.Structure):
     _fields_ = [
         ('z', ctypes.c_void_p), ('c', ctypes.c_void_p), ('embed_w', ctypes.c_void_p), ('embed_b', ctypes.c_void_p),
@@ -270,6 +291,9 @@ def load():
             'ide3d_mapping_supported': [],
             'ide3d_skip_upsample_add_cl': [vp, ctypes.POINTER(i64 * 4), vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, vp],
             'ide3d_bilinear_up2_split': [vp, i32, i32, i32, i32, ctypes.POINTER(vp * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(i32 * 3), vp],
+            'ide3d_lowres_layers_supported': [i32, i32, i32, ctypes.POINTER(i32), i32, i32],
+            'ide3d_lowres_workspace_bytes': [ctypes.POINTER(_LowresParams)],
+            'ide3d_lowres_group': [ctypes.POINTER(_LowresParams), vp],
         }
         for name, argtypes in protos.items():
             fn = getattr(lib, name)          # AttributeError here = header / library mismatch
@@ -287,6 +311,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_modconv_plan', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
     'ide3d_style_demod_batch', 'ide3d_fold_heads_batch',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
+    'ide3d_lowres_layers_supported', 'ide3d_lowres_workspace_bytes', 'ide3d_lowres_group',
 )
 
 
@@ -399,7 +424,7 @@ _scope_finalizers = {}
 
 def _drop_owner(domain):
     _scope_finalizers.pop(domain, None)
-    for cache in (ModconvPlugin._ws, MappingPlugin._ws):
+    for cache in (ModconvPlugin._ws, MappingPlugin._ws, LowresPlugin._ws):
         for k in [k for k in cache if domain in k]:
             del cache[k]
 
@@ -1268,7 +1293,96 @@ class ResamplePlugin:
         return outs
 
 
+class LowresPlugin:
+    """The low-resolution block group of the backbone in one launch (csrc/lowres.hip, include/ide3d_hip.h `ide3d_lowres_group`)."""
+    # workspace cache: key -> [buffer (zero-filled once: the halo slots of the activation images are never written), per layer (weakref(weight), version)]
+    _ws = {}
+
+    @staticmethod
+    def layers_supported(n, C, res0, ups, arith=0):
+        arr = (ctypes.c_int32 * len(ups))(*[int(u) for u in ups])
+        return int(load().ide3d_lowres_layers_supported(int(n), int(C), int(res0), arr, len(ups), int(arith)))
+
+    @staticmethod
+    def persistent_default():
+        return os.environ.get('IDE3D_LOWRES_PERSISTENT', '0') == '1'
+
+    @staticmethod
+    def group(x0, layers, heads, fir, persistent=None, arith=0):
+        """x0 [C, r, r] (shared by the batch) or [n, C, r, r]; layers: dicts(weight [C, C, 3, 3], styles [n, C], dcoefs [n, C], noise [res, res] | None
+        (x noise_strength already), bias [C] | None, act_gain, clamp (< 0: none), up (1 | 2), head (index | -1)); heads: dicts(w [n, O, C], bias [O] |
+        None, clamp).  Returns (x_out [n, C, res, res], [skip_k [n, O, res_k, res_k]])."""
+        lib = load()
+        n, C = layers[0]['styles'].shape
+        dev = x0.device
+        _require(1 <= len(layers) <= LOWRES_MAX_LAYERS and len(heads) <= LOWRES_MAX_HEADS, 'lowres_group: too many layers / heads')
+        _require(x0.is_cuda and x0.dtype == torch.float32 and x0.is_contiguous() and x0.shape[-3] == C and x0.shape[-1] == x0.shape[-2], 'lowres_group: x0 must be contiguous float32 [C, r, r] or [n, C, r, r]')
+        _require(fir.is_cuda and fir.dtype == torch.float32 and fir.is_contiguous() and tuple(fir.shape) == (4, 4) and fir.device == dev, 'lowres_group: fir must be a float32 [4, 4] filter on the device of x0')
+        arith = int(arith) or int(lib.ide3d_get_conv_arithmetic())
+        p = _LowresParams()
+        p.x0, p.x0_batch_stride = x0.data_ptr(), (x0.stride(0) if x0.ndim == 4 else 0)
+        p.fir = fir.data_ptr()
+        p.n, p.C, p.res0, p.nlayers, p.nheads, p.arith = n, C, x0.shape[-1], len(layers), len(heads), arith
+        p.persistent = int(LowresPlugin.persistent_default() if persistent is None else bool(persistent))
+        keep, res, head_res = [], x0.shape[-1], {}
+        for l, L in enumerate(layers):
+            q = p.layers[l]
+            w = L['weight']
+            _require(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (C, C, 3, 3) and w.device == dev, f'lowres_group: layer {l}: weight must be contiguous float32 [C, C, 3, 3]')
+            q.weight = w.data_ptr()
+            res = res * 2 if int(L['up']) == 2 else res
+            for name, shape in (('styles', (n, C)), ('dcoefs', (n, C)), ('noise', (res, res)), ('bias', (C,))):
+                t = L.get(name)
+                if t is None:
+                    _require(name in ('noise', 'bias'), f'lowres_group: layer {l}: {name} is required')
+                    continue
+                t = t.contiguous(); keep.append(t)
+                _require(t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == shape and t.device == dev, f'lowres_group: layer {l}: {name} must be float32 {shape} on the device of x0')
+                setattr(q, name, t.data_ptr())
+            q.act_gain, q.clamp, q.up, q.head = float(L['act_gain']), float(L['clamp']), int(L['up']), int(L.get('head', -1))
+            if q.head >= 0:
+                head_res[q.head] = res
+        key = (tuple(L['weight'].data_ptr() for L in layers), n, C, x0.shape[-1], tuple(int(L['up']) for L in layers), dev.index, _ws_domain(dev), arith)
+        ent = LowresPlugin._ws.get(key)
+        if ent is None:
+            nbytes = lib.ide3d_lowres_workspace_bytes(ctypes.byref(p))
+            _require(nbytes > 0, 'lowres_group: unsupported configuration')
+            if len(LowresPlugin._ws) > 64:
+                for k_dead in [k_ for k_, e_ in LowresPlugin._ws.items() if any(r() is None for r, _ in e_[1])]:
+                    del LowresPlugin._ws[k_dead]
+            ent = LowresPlugin._ws[key] = [torch.zeros([nbytes // 4 + 1], dtype=torch.float32, device=dev), [(lambda: None, None)] * len(layers)]
+        for l, L in enumerate(layers):
+            ref, ver = ent[1][l]
+            p.layers[l].weights_packed = int(ref() is L['weight'] and ver == L['weight']._version)
+        p.workspace, p.workspace_bytes = ent[0].data_ptr(), ent[0].numel() * 4
+        skips = []
+        for k, H in enumerate(heads):
+            q = p.heads[k]
+            w = H['w'].reshape(n, -1, C)
+            _require(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.device == dev, f'lowres_group: head {k}: folded weights must be contiguous float32 [n, O, C]')
+            _require(k in head_res, f'lowres_group: head {k} is not attached to a layer')
+            O = w.shape[1]
+            keep.append(w)
+            q.w, q.O, q.clamp = w.data_ptr(), O, float(H['clamp'])
+            b = H.get('bias')
+            if b is not None:
+                b = b.contiguous(); keep.append(b)
+                _require(b.is_cuda and b.dtype == torch.float32 and tuple(b.shape) == (O,) and b.device == dev, f'lowres_group: head {k}: bias must be float32 [O]')
+                q.bias = b.data_ptr()
+            sk = torch.empty([n, O, head_res[k], head_res[k]], dtype=torch.float32, device=dev)
+            q.skip = sk.data_ptr()
+            skips.append(sk)
+        x_out = torch.empty([n, C, res, res], dtype=torch.float32, device=dev)
+        p.x_out = x_out.data_ptr()
+        with _dev_guard(dev):
+            rc = lib.ide3d_lowres_group(ctypes.byref(p), _stream(x0))
+        _check(rc, 'lowres_group')
+        ent[1] = [(weakref.ref(L['weight']), L['weight']._version) for L in layers]
+        return x_out, skips
+
+
 PLUGINS = {
+    'lowres_plugin': LowresPlugin,
     'bias_act_plugin': BiasActPlugin,
     'upfirdn2d_plugin': Upfirdn2dPlugin,
     'filtered_lrelu_plugin': FilteredLReluPlugin,

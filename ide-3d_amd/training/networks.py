@@ -485,6 +485,109 @@ def _dual_head(x, torgb, toseg, w):
     return y[:, :co], y[:, co:]
 
 
+_lowres_plugin = None
+
+
+def _lowres_init():
+    global _lowres_plugin
+    if _lowres_plugin is None:
+        _lowres_plugin = custom_ops.get_plugin(module_name='lowres_plugin', sources=['lowres.hip'])
+    return True
+
+
+def _hooked(*modules):
+    """True when a forward (pre-)hook sits on one of `modules` (or globally): the hook wants that module's own call."""
+    from torch.nn.modules import module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks for m in modules)
+
+
+def lowres_group_forward(blocks, ws_per_block, noise_mode='const', force_fp32=False, **other_kwargs):
+    """The leading dual-path blocks of a backbone — 4^2, 8^2, ... for as long as all images' maps of a layer fit one CU's LDS beside a weight
+    slice — in ONE launch of csrc/lowres.hip (`ide3d_lowres_group`) instead of 2-4 launches per layer + 3 per pair of heads.
+    Semantics: `SegSynthesisBlock.forward` of those blocks (reference inversion/networks.py:966-1139) with `SynthesisLayer` (:330-514)
+    and `ToRGBLayer` (:670-713) in inference: const noise or none, fp32 blocks, 'skip' architecture, 3x3 layers of one width C, lrelu, the
+    [1, 3, 3, 1] resample filter, products in the bf16x6 / bf16x3 arithmetic (`hip_plugin.conv_arithmetic`).  Anything else — autograd, a
+    forward hook on one of the blocks or layers (viz/renderer.py:437), random noise, fp16 blocks, other arithmetics, `IDE3D_NO_LOWRES_GROUP` —
+    keeps the per-layer path: returns None.
+    Returns (x, img, seg, next_block, resume): the running tensors in front of `blocks[next_block]`; `resume` = x is already the output of that
+    block's conv0 (the group may end in the middle of a block: `forward(..., _resume_after_conv0=True)`)."""
+    if os.environ.get('IDE3D_NO_LOWRES_GROUP') or not use_hip_modconv or other_kwargs or noise_mode not in ('const', 'none'):
+        return None
+    if not blocks or len(blocks) != len(ws_per_block):
+        return None
+    b0 = blocks[0]
+    ws0 = ws_per_block[0]
+    if not (torch.is_tensor(ws0) and ws0.is_cuda and ws0.dtype == torch.float32) or (torch.is_grad_enabled() and ws0.requires_grad):
+        return None
+    if b0.in_channels != 0 or b0.use_single_layer or not hasattr(b0, 'const') or not _inference_on_gpu(b0.const, b0.conv1.weight):
+        return None
+    from torch_utils import hip_plugin
+    if hip_plugin.conv_arithmetic() not in ('bf16x6', 'bf16x3'):
+        return None
+    C, n = b0.out_channels, ws0.shape[0]
+    if C % 32 != 0 or n > 8:
+        return None
+    # the layers, in order, of every leading block that qualifies
+    cand = []          # (block index, 'conv0' | 'conv1', layer)
+    for bi, blk in enumerate(blocks):
+        ok = (blk.architecture == 'skip' and not blk.use_single_layer and blk.out_channels == C and (bi == 0 or blk.in_channels == C)
+              and not (blk.use_fp16 and not force_fp32) and not getattr(blk, 'skip_channels_last', False)
+              and blk.torgb.conv_clamp == blk.toseg.conv_clamp and blk.torgb.weight.shape[2] == 1 and blk._filter_is_1331()
+              and blk.resolution == b0.resolution << bi
+              and not _hooked(blk, blk.conv1, blk.torgb, blk.toseg, *([blk.conv0] if bi else [])))
+        if not ok:
+            break
+        for name in (('conv1',) if bi == 0 else ('conv0', 'conv1')):
+            lay = getattr(blk, name)
+            if not (lay.activation == 'lrelu' and lay.weight.shape == (C, C, 3, 3) and lay.padding == 1 and lay.up == (2 if name == 'conv0' else 1)
+                    and _inference_on_gpu(ws0, lay.weight, lay.bias) and lay.weight.is_contiguous()
+                    and (not lay.use_noise or noise_mode == 'none' or lay.noise_const.shape[-1] == blk.resolution)):
+                ok = False
+                break
+            cand.append((bi, name, lay))
+        if not ok:
+            cand = [c for c in cand if c[0] < bi]
+            break
+    if not cand or not _lowres_init():
+        return None
+    ups = [lay.up for _, _, lay in cand]
+    fit = _lowres_plugin.layers_supported(n, C, b0.resolution, ups)
+    if fit < 1:
+        return None
+    cand = cand[:fit]
+    last_bi, last_name, _ = cand[-1]
+    resume = last_name == 'conv0'
+    nheads = last_bi if resume else last_bi + 1                    # heads of every COMPLETE block
+    if nheads > hip_plugin.LOWRES_MAX_HEADS or (nheads == 0):
+        return None
+    layers, heads = [], []
+    for bi, name, lay in cand:
+        blk, wsb = blocks[bi], ws_per_block[bi]
+        w = wsb[:, (0 if (bi == 0 or name == 'conv0') else 1)]
+        styles, dcoefs = _styles_and_dcoefs(lay.affine, w, lay.weight, True)
+        noise = None
+        if lay.use_noise and noise_mode == 'const':
+            noise = _scaled_const_noise(lay.noise_const, lay.noise_strength)
+        layers.append(dict(weight=lay.weight, styles=styles, dcoefs=dcoefs, noise=noise, bias=lay.bias, act_gain=lay.act_gain,
+                           clamp=(-1.0 if lay.conv_clamp is None else lay.conv_clamp), up=lay.up,
+                           head=(bi if (name == 'conv1' and bi < nheads) else -1)))
+    for bi in range(nheads):
+        blk, wsb = blocks[bi], ws_per_block[bi]
+        w = wsb[:, blk.num_conv]
+        wcat = _take_prefetched(blk.torgb, w) if _prefetch_table() else None
+        if wcat is None:
+            wcat = _folded_head_weights(blk.torgb, blk.toseg, w)
+        if wcat is None:
+            return None
+        heads.append(dict(w=wcat, bias=_cat_cached(blk.torgb.bias, blk.toseg.bias), clamp=(-1.0 if blk.torgb.conv_clamp is None else blk.torgb.conv_clamp)))
+    x, skips = _lowres_plugin.group(b0.const.detach(), layers, heads, b0.resample_filter)
+    co = blocks[0].torgb.weight.shape[0]
+    skip = skips[-1]
+    return x, skip[:, :co], skip[:, co:], nheads, resume
+
+
 @persistence.persistent_class
 class FullyConnectedLayer(torch.nn.Module):
     """Equalised-learning-rate dense layer (reference networks.py:136-165)."""
@@ -869,6 +972,7 @@ class SegSynthesisBlock(torch.nn.Module):
 
     def forward(self, x, img, seg, ws, force_fp32=False, fused_modconv=None, block_noise=None, disable_rgb=False, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        resume_after_conv0 = bool(layer_kwargs.pop('_resume_after_conv0', False))
         w_iter = iter(ws.unbind(dim=1))
         dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
         memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
@@ -892,7 +996,10 @@ class SegSynthesisBlock(torch.nn.Module):
         else:
             x = x.to(dtype=dtype, memory_format=memory_format)
             layer_kwargs['input_noise'] = block_noise[:, 0:1] if block_noise is not None else None
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            if resume_after_conv0:
+                next(w_iter)          # x already is conv0's output (lowres_group_forward ended inside this block)
+            else:
+                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
             if not self.use_single_layer:
                 layer_kwargs['input_noise'] = block_noise[:, 1:2] if block_noise is not None else None
                 x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)

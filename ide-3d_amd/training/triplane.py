@@ -322,8 +322,17 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
     def backbone(self, voxel_ws, **block_kwargs):
         """ws -> (texture tri-plane, semantic tri-plane); pose independent."""
         x_v = img_v = seg_v = None
-        for res, cur_ws in zip(self.voxel_block_resolutions, voxel_ws):
-            x_v, img_v, seg_v = getattr(self, f'vb{res}')(x_v, img_v, cur_ws, condition_img=seg_v, **block_kwargs)
+        blocks = [getattr(self, f'vb{res}') for res in self.voxel_block_resolutions]
+        start, resume = 0, False
+        # the 4^2 .. 16^2 / 32^2 blocks in one launch when that applies (GPU inference, default arithmetic, no hooks on them): csrc/lowres.hip
+        grp = networks.lowres_group_forward(blocks, voxel_ws, **block_kwargs) if (voxel_ws and torch.is_tensor(voxel_ws[0]) and voxel_ws[0].is_cuda) else None
+        if grp is not None:
+            x_v, img_v, seg_v, start, resume = grp
+        for i, (block, cur_ws) in enumerate(zip(blocks, voxel_ws)):
+            if i < start:
+                continue
+            extra = dict(_resume_after_conv0=True) if (resume and i == start) else {}
+            x_v, img_v, seg_v = block(x_v, img_v, cur_ws, condition_img=seg_v, **block_kwargs, **extra)
         return img_v, seg_v
 
     @contextlib.contextmanager

@@ -490,6 +490,60 @@ typedef struct ide3d_fold_job {
 int ide3d_style_demod_batch(const ide3d_style_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream);
 int ide3d_fold_heads_batch(const ide3d_fold_job* jobs, int32_t njobs, int32_t n, int32_t wdim, void* stream);
 
+/* ---- the low-resolution block group of the backbone in one launch (round 6, ABI 7) ------------------- */
+/*
+ * The first blocks of the dual-path StyleGAN2 backbone (inversion/networks.py:966-1139: 4^2, 8^2, 16^2 ... while all images' maps of a layer
+ * fit one CU's LDS beside a weight slice) — every 3x3 / up-sampling SynthesisLayer (networks.py:330-514) with its noise, bias, lrelu,
+ * gain and clamp, the 4x4 FIR of the up-sampling layers (conv2d_resample.py:112-129), the toRGB + toSeg heads (networks.py:670-713) and the
+ * skip accumulation `img = upsample2d(img) + y` (networks.py:1100,1121) — as ONE launch (persistent != 0: phases separated by a grid barrier)
+ * or one launch per phase (persistent == 0).  All layers have C input and C output channels (C % 32 == 0); fp32 in / fp32 out; products in
+ * the bf16x6 (or bf16x3) arithmetic of ide3d_set_conv_arithmetic, heads in plain fp32 FMAs.  Inference only.
+ *   layer l: up = 1: y = lrelu(d * conv3x3(x * s) + noise + b, 0.2) * act_gain, clamped;   up = 2: the same with
+ *            conv_transpose2d(stride 2) -> upfirdn2d(f, pad 1, gain 4) in place of the convolution (output 2 x the input resolution);
+ *            head >= 0: heads[head] is applied to this layer's output: skip = clamp(W[n] y + b) + upsample2d(heads[head - 1].skip, f).
+ *   x0: the group's input [C, res0, res0] (x0_batch_stride == 0: the learned constant, shared by the batch) or [n, C, res0, res0].
+ *   x_out: the last layer's output [n, C, res, res] NCHW.  heads[k].skip [n, O, res_k, res_k] NCHW (every head's skip image is written).
+ * Returns IDE3D_ENOKERNEL when the arithmetic is fp32 / f16x3 or the layers do not fit (ask ide3d_lowres_layers_supported): callers then
+ * run the layers one by one (ide3d_modconv2d ...).
+ */
+#define IDE3D_LOWRES_MAX_LAYERS 8
+#define IDE3D_LOWRES_MAX_HEADS 4
+typedef struct ide3d_lowres_layer {
+    const float* weight;      /* [C, C, 3, 3] */
+    const float* styles;      /* [n, C] */
+    const float* dcoefs;      /* [n, C] */
+    const float* noise;       /* [res, res], already multiplied by noise_strength, or NULL */
+    const float* bias;        /* [C] or NULL */
+    float act_gain, clamp;    /* clamp < 0: none */
+    int32_t up;               /* 1 or 2 */
+    int32_t head;             /* index into heads[], or -1 */
+    int32_t weights_packed;   /* 1: the workspace already holds this layer's packed weights (same weight version, same arithmetic) */
+    int32_t reserved;
+} ide3d_lowres_layer;
+typedef struct ide3d_lowres_head {
+    const float* w;           /* [n, O, C] per-image folded weights (ide3d_fold_heads) */
+    const float* bias;        /* [O] or NULL */
+    float* skip;              /* out [n, O, res, res] */
+    float clamp;
+    int32_t O;
+} ide3d_lowres_head;
+typedef struct ide3d_lowres_params {
+    const float* x0; int64_t x0_batch_stride;
+    const float* fir;         /* [4, 4] resample filter (upfirdn2d.setup_filter([1, 3, 3, 1])) */
+    float* x_out;
+    void* workspace; int64_t workspace_bytes;
+    int32_t n, C, res0, nlayers, nheads;
+    int32_t arith;            /* 0 = process default; only 6 (bf16x6) and 3 (bf16x3) have this form */
+    int32_t persistent;
+    int32_t reserved;
+    ide3d_lowres_layer layers[IDE3D_LOWRES_MAX_LAYERS];
+    ide3d_lowres_head heads[IDE3D_LOWRES_MAX_HEADS];
+} ide3d_lowres_params;
+/* number of leading layers (ups[l] in {1, 2}) of a group that starts at res0 which ide3d_lowres_group accepts for this batch size */
+int32_t ide3d_lowres_layers_supported(int32_t n, int32_t C, int32_t res0, const int32_t* ups, int32_t nlayers, int32_t arith);
+int64_t ide3d_lowres_workspace_bytes(const ide3d_lowres_params* p);     /* only n, C, res0, nlayers, arith and layers[].up are read */
+int ide3d_lowres_group(const ide3d_lowres_params* p, void* stream);
+
 /* ---- output post-processing -------------------------------------------- */
 /* ---- mapping network ---------------------------------------------------------------------- */
 /*
