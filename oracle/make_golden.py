@@ -390,6 +390,35 @@ def gen_encoder():
     save('encoder', cases)
 
 
+def gen_bisenet():
+    """`BiSeNet(n_classes=20)` forward (inversion/BiSeNet.py:229-256) in eval mode on a synthetic state dict that is a function of the parameter
+    NAMES (oracle/face_parsing.py `synthetic_state_dict`: the 53 MB of weights are not stored), plus the label pipeline of
+    dnnlib/seg_tools.py:100-123 restated on the logits (that module imports torchvision, which is not installed: `id_remap` / `scatter` are the
+    two-line bodies executed from the reference source text, as for gen_post)."""
+    import re
+    from inversion.BiSeNet import BiSeNet
+    from oracle import face_parsing as ofp
+    torch.manual_seed(5)
+    net = BiSeNet(n_classes=20).eval()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(ofp.synthetic_state_dict(shapes))
+    g = torch.Generator().manual_seed(23)
+    cases = []
+    for n, h, w in ((2, 64, 96), (1, 96, 64)):
+        x = torch.randn(n, 3, h, w, generator=g)
+        with torch.no_grad():
+            out = net(x)[0]
+        cases.append(dict(cfg=dict(fn='bisenet', n_classes=20, shapes=shapes), in_x=x, out_logits=out))
+    ns = dict(torch=torch, F=torch.nn.functional)
+    seg_src = open(os.path.join(ref_import.REFERENCE_ROOT, 'dnnlib', 'seg_tools.py')).read()
+    exec(re.search(r'remap_list = .*?\n', seg_src).group(0) + re.search(r'def id_remap\(.*?\n\n', seg_src, re.S).group(0)
+         + re.search(r'def scatter\(.*?return input_label\.scatter_\(1, condition_img\.long\(\), 1\)\n', seg_src, re.S).group(0), ns)
+    logits = cases[1]['out_logits']
+    seg = ns['id_remap'](logits.argmax(1, keepdim=True), 'celebahq')
+    cases.append(dict(cfg=dict(fn='labels', case=1), out_remap=seg.to(torch.uint8), out_onehot=ns['scatter'](seg, label_size=(96, 64)).to(torch.uint8)))
+    save('bisenet', cases)
+
+
 def gen_post():
     """mask2color / layout_grid / create_samples.  dnnlib/seg_tools.py and extract_shapes.py import packages that are
     not installed (torchvision, BiSeNet, mrcfile), so their few-line function bodies are executed here from the
@@ -433,4 +462,5 @@ if __name__ == '__main__':
     gen_networks()
     gen_generator()
     gen_encoder()
+    gen_bisenet()
     gen_post()

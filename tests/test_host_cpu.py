@@ -467,3 +467,30 @@ def test_row_floats_readable_is_the_distance_to_the_end_of_storage():
     assert hip_plugin._row_floats_readable(base[:, :, :8:2]) == 20 + 2 * 20  # H-strided view ending two rows earlier
     assert hip_plugin._row_floats_readable(base.flip(3)) == 0 if any(s <= 0 for s in base.flip(3).stride()) else True
     assert hip_plugin._row_floats_readable(torch.zeros(4, 5)) == 0           # not rank 4: no promise
+
+
+def test_face_parser_state_dict_layout_and_cpu_path(golden):
+    """training/face_parsing.py: the state dict has the reference BiSeNet's keys and shapes (so `segNet-20Class.pth`, dnnlib/seg_tools.py:128,
+    loads), and its CPU forward reproduces the reference run of tests/golden/bisenet.npz; the label pipeline (argmax, id_remap, scatter) too."""
+    from training import face_parsing
+    from oracle import face_parsing as ofp
+    cases = golden('bisenet').select(fn='bisenet')
+    shapes = cases[0][0]['shapes']
+    net = face_parsing.BiSeNet(n_classes=20).eval()
+    mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert list(mine) == list(shapes), 'state dict keys (and their order) differ from the reference BiSeNet'
+    assert mine == shapes
+    net.load_state_dict(ofp.synthetic_state_dict(shapes))
+    for cfg, a in cases:
+        with torch.no_grad():
+            out, aux16, aux32 = net(t(a['in_x']))
+        assert aux16 is None and aux32 is None
+        assert_close(out, a['out_logits'], rtol=0, atol=2e-5 * float(np.abs(a['out_logits']).max()), what='BiSeNet logits (CPU path)')
+    (cfg, a), = golden('bisenet').select(fn='labels')
+    logits = t(cases[1][1]['out_logits'])
+    seg = face_parsing.id_remap(logits.argmax(1, keepdim=True), 'celebahq')
+    assert np.array_equal(seg.numpy().astype(np.uint8), a['out_remap'])
+    assert np.array_equal(face_parsing.scatter(seg, label_size=tuple(logits.shape[2:])).numpy().astype(np.uint8), a['out_onehot'])
+    # parsing_img / face_parsing shapes (dnnlib/seg_tools.py:100-123): any input size -> one-hot at 512 x 512
+    img, onehot = face_parsing.parsing_img(lambda x: (logits,), t(cases[1][1]['in_x']), return_mask=False)
+    assert onehot.shape == (1, 1, 96, 64)
