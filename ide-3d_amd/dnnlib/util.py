@@ -138,17 +138,67 @@ def _sample_from_triplane_ref(coordinates, grid):
     return xy + yz + xz
 
 
+# ---- is a plain [B, M, 3] coordinate tensor a flattened ray grid? ------------------------------------------------------------------
+# The LDS-staged gather kernel (csrc/triplane_tile.hip) tiles the samples as [rays_h, rays_w, steps]; its results are bit-equal to the
+# flat kernel's for ANY coordinates and ANY factorisation of M (tiles whose footprint does not fit LDS read the planes directly), so the
+# factorisation is purely a speed hint — and a reference caller does not pass one (volumetric_rendering.py:123-136 returns points that the
+# generator reshapes to [B, R * S, 3] before `sample_from_triplane`).  The first call with a given M looks at the data once: the samples
+# of one ray are collinear, so the ray length S is the index of the first point that leaves the line through points 0 and 1; the row
+# length is where the first samples of consecutive rays stop advancing by one pixel step.  That costs one small device-to-host copy (a synchronisation), so the answer is cached per (M, device) and the
+# look is skipped while a hipGraph is being captured (the flat kernel runs then, unless the answer is cached already).
+_ray_grid_cache = {}
+
+
+def _guess_ray_grid(coordinates):
+    if coordinates.ndim != 3 or coordinates.shape[2] != 3 or coordinates.requires_grad:
+        return None
+    m = int(coordinates.shape[1])
+    key = (m, coordinates.device.index)
+    if key in _ray_grid_cache:
+        return _ray_grid_cache[key]
+    if m < 256 or torch.cuda.is_current_stream_capturing():
+        return None
+    head = coordinates[0, :min(m, 2048)].detach().double().cpu()          # (one synchronisation per new M)
+    found = None
+    d = head[1] - head[0]
+    if float(d.norm()) > 0:
+        rel = head - head[0]
+        off = torch.linalg.cross(rel, d.expand_as(rel)).norm(dim=1)          # distance from the line through points 0 and 1, times |d|
+        bad = (off > 1e-4 * float(d.norm()) * rel.norm(dim=1).clamp_min(float(d.norm()))).nonzero()
+        if bad.numel():
+            s = int(bad[0])
+            if s >= 4 and s % 4 == 0 and m % s == 0:
+                rays = m // s
+                # row length: the first samples of consecutive rays advance by one pixel step along an image row and jump back at its end
+                first = coordinates[0, ::s][:min(rays, 4096)].detach().double().cpu()
+                step = (first[1:] - first[:-1]).norm(dim=1)
+                jump = (step > 4 * float(step[0])).nonzero() if step.numel() and float(step[0]) > 0 else step.new_zeros(0)
+                w = int(jump[0]) + 1 if jump.numel() else int(round(rays ** 0.5))
+                if w >= 8 and rays % w == 0 and w % 8 == 0 and (rays // w) % 8 == 0:
+                    found = (rays // w, w, s)
+    if len(_ray_grid_cache) > 256:
+        _ray_grid_cache.clear()
+    _ray_grid_cache[key] = found
+    return found
+
+
 def sample_from_triplane(coordinates, grid, impl='cuda', ray_grid=None):
     """Sum of the xy / yz / xz plane look-ups: coordinates [B, M, 3], grid [B, 3*C, H, W] -> [B*M, C]
     (reference util.py:580-599; planes are square in every caller).
 
     `ray_grid=(rays_h, rays_w, steps)` (ours, optional): the M samples are a flattened [rays_h, rays_w, steps] ray grid, as
-    produced by `transform_sampled_points`; lets the HIP library stage shared texels in LDS.  Results do not depend on it."""
+    produced by `transform_sampled_points`; lets the HIP library stage shared texels in LDS.  Results do not depend on it, and a
+    caller need not pass it: without the hint the first call with a given M checks the data once (`_guess_ray_grid`);
+    `ray_grid=False` forces the flat kernel."""
     assert impl in ['ref', 'cuda']
     use_hip = (impl == 'cuda' and grid.device.type == 'cuda' and grid.dtype == torch.float32
                and coordinates.dtype == torch.float32 and grid.shape[2] == grid.shape[3]
                and not grid_sample_gradfix.enabled)
     if use_hip and _triplane_init():
+        if ray_grid is None:
+            ray_grid = _guess_ray_grid(coordinates)          # the call exactly as the reference spells it (util.py:580): no hint needed
+        elif ray_grid is False:
+            ray_grid = None                                  # the flat kernel, whatever the coordinates look like (tests, roofline rows)
         return _TriplaneSampleHip.apply(coordinates, grid, ray_grid)
     return _sample_from_triplane_ref(coordinates, grid)
 

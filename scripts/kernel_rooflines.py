@@ -150,6 +150,9 @@ def cases(device):
     out.append(('tri-plane gather, ray-grid kernel (N=4, 1 tri-plane)', 'triplane_sample_tile', 'hbm', gbytes,
                 lambda: util.sample_from_triplane(coords, planes, ray_grid=(64, 64, 96))))
     out.append(('tri-plane gather, flat kernel (N=4, 1 tri-plane)', 'triplane_sample_cl2', 'hbm', gbytes,
+                lambda: util.sample_from_triplane(coords, planes, ray_grid=False)))
+    # the call exactly as dnnlib/util.py:580 spells it: the ray grid is recognised from the data (first call, cached per M)
+    out.append(('tri-plane gather, flat call (no hint: ray grid recognised from the data)', 'triplane_sample_tile', 'hbm', gbytes,
                 lambda: util.sample_from_triplane(coords, planes)))
 
     # ---- a13 / fused renderer -------------------------------------------------------------------------------------------

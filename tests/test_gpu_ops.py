@@ -409,10 +409,23 @@ def test_triplane_ray_grid_kernel_equals_flat_kernel(gpu_device):
     cases.append(('random + wild', rnd.to(gpu_device), (16, 16, 8)))
     cases.append(('grid not covered by the tile kernel', frustum((12, 20), 10, (0.1, 0.2, 0.3)), (12, 20, 10)))
     for name, co, rg in cases:
-        flat = util.sample_from_triplane(co, planes)
+        flat = util.sample_from_triplane(co, planes, ray_grid=False)
         tiled = util.sample_from_triplane(co, planes, ray_grid=rg)
         assert torch.equal(torch.nan_to_num(flat, nan=123.0), torch.nan_to_num(tiled, nan=123.0)), name
-    assert _calls('triplane_sample_rays') == len(cases)
+    assert _calls('triplane_sample_rays') == len(cases) and _calls('triplane_sample') == len(cases)
+    # the call exactly as the reference spells it (dnnlib/util.py:580: no hint): the ray grid is recognised from the data on the first call with
+    # this M (cached afterwards) and the LDS-staged kernel runs; coordinates that are no ray grid keep the flat kernel; results bit-equal
+    util._ray_grid_cache.clear()
+    for name, co, rg in cases[:3]:
+        before = _calls('triplane_sample_rays')
+        plain = util.sample_from_triplane(co, planes)
+        assert _calls('triplane_sample_rays') == before + 1, name
+        assert util._ray_grid_cache[(co.shape[1], gpu_device.index)] in (rg, (rg[1], rg[0], rg[2])), (name, util._ray_grid_cache)     # (rows, row length, steps)
+        assert torch.equal(torch.nan_to_num(plain, nan=123.0), torch.nan_to_num(util.sample_from_triplane(co, planes, ray_grid=False), nan=123.0)), name
+    util._ray_grid_cache.clear()
+    before = _calls('triplane_sample')
+    util.sample_from_triplane(cases[3][1], planes)
+    assert _calls('triplane_sample') == before + 1 and util._ray_grid_cache[(cases[3][1].shape[1], gpu_device.index)] is None
     co = cases[0][1]
     idx = torch.arange(0, co.shape[1], 1009, device=gpu_device)
     ref = fast_ops.sample_from_triplane(co[:, idx].cpu(), planes.cpu().contiguous())
