@@ -270,7 +270,38 @@ def _finite(o):
     return o
 
 
-OPTIONAL_KEYS = ('roofline_worst', 'dropin_b1', 'parity_live', 'gather_overlap', 'frames_per_s_by_rank', 'timing', 'by_conv_arithmetic', 'parity', 'roofline_step')
+OPTIONAL_KEYS = ('gpu_state', 'roofline_worst', 'dropin_b1', 'parity_live', 'gather_overlap', 'frames_per_s_by_rank', 'timing', 'by_conv_arithmetic', 'parity', 'roofline_step')
+
+
+def gpu_state_under_load(enqueue, busy_steps=300):
+    """Clock / power of GPU 0 WHILE the render step runs: `busy_steps` steps are enqueued (asynchronous graph replays: ~1.3 s of GPU work), then
+    `rocm-smi --showclocks --showpower --json` is read on the host while they execute.  The boxes of the pool differ by up to 10 % under bf16 matrix
+    load with the same binary (DESIGN.md 5.7): this puts the clock the box actually ran at next to every number (VERDICT r5 #8)."""
+    import shutil
+    import subprocess
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(exe):
+        return None
+    try:
+        for i in range(busy_steps):
+            enqueue(i)
+        t0 = time.perf_counter()
+        res = subprocess.run([exe, '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=20)
+        took = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        still_busy = time.perf_counter() - t0 - took > 0.02          # the queue outlived the query: it was sampled under load
+        card = next(iter(json.loads(res.stdout).values()))
+        pick = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if ('sclk' in kl or 'mclk' in kl) and 'speed' in kl:
+                pick[kl.split()[0] + '_mhz'] = v.strip('()').replace('Mhz', '').replace('MHz', '')
+            elif 'power' in kl and '(w)' in kl:
+                pick['power_w'] = v
+        pick['sampled_under_load'] = bool(still_busy)
+        return pick
+    except Exception as e:      # noqa: BLE001 - diagnostics only
+        return {'error': f'{type(e).__name__}: {e}'[:120]}
 
 
 def compact_line(out, limit=None):
@@ -607,6 +638,11 @@ def main():
         if cpu:
             out['metric'] = 'DRY RUN (CPU tensors, tiny generator, gloo): launcher / protocol self-test, not a measurement'
             out['data'] = 'synthetic (cpu dry run)'
+        if not cpu and world == 1:
+            state = gpu_state_under_load(lambda i: step(i))
+            full['gpu_state_under_load'] = state
+            if state and 'error' not in state:
+                out['gpu_state'] = {k: state[k] for k in list(state)[:5]}
         pin = None
         if not cpu and not args.no_parity:
             par, got = check_parity(render, device)

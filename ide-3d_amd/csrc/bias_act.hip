@@ -7,6 +7,7 @@
 // bias stride allows it.  Algorithmic traffic: 2 * numel * sizeof(T) (+ xref/yref/dy reads for
 // the gradient forms).
 #include "common.h"
+#include "knobs.h"
 
 namespace ide3d {
 
@@ -182,7 +183,7 @@ static int launch_bias_act(const void* x, const void* b, const void* xref, const
     const bool can_vec = aligned(x) && aligned(xref) && aligned(yref) && aligned(dy) && aligned(y);
     int64_t nvec = can_vec ? size_x / VEC : 0;
     // forward pass over whole planes: the bias is constant inside a plane of step_b elements, planes of >= 256 vectors
-    if (nvec > 0 && grad == 0 && !xref && !yref && !dy && !getenv("IDE3D_BIAS_ACT_NO_PLANES")) {
+    if (nvec > 0 && grad == 0 && !xref && !yref && !dy && !knob_live("IDE3D_BIAS_ACT_NO_PLANES")) {
         const int64_t plane = b ? step_b : size_x;
         if (plane % VEC == 0 && size_x % plane == 0 && plane / VEC >= 256 && plane / VEC < (1ll << 31) && size_b < (1ll << 31)) {
             const int64_t vpp = plane / VEC, chunks = (vpp + 256 * BA_ITER - 1) / (256 * BA_ITER), blocks = (size_x / plane) * chunks;

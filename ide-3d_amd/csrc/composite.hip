@@ -16,6 +16,7 @@
 //      and (through L1, same lines as phase 1's sigma reads) exactly once from HBM.
 // HBM roofline: rays*steps*(ch+2)*4 bytes in, rays*(ch+1+steps)*4 out.
 #include "common.h"
+#include "knobs.h"
 #include <stdlib.h>
 
 namespace ide3d {
@@ -220,14 +221,14 @@ extern "C" int ide3d_composite(const float* rgb_sigma, const float* z_vals, cons
         // LDS-staged path: contiguous, 16-byte aligned ray blocks that fit four to a workgroup
         const int64_t block = (int64_t)steps * (ch + 1);
         const size_t lds = (size_t)4 * (block + ((steps + 3) & ~3)) * sizeof(float);
-        static const bool off = getenv("IDE3D_COMPOSITE_NO_LDS") != nullptr;
+        const bool off = knobs().composite_no_lds;
         if (!off && block % 4 == 0 && block <= 40 * 256 && lds <= 160 * 1024 && ((reinterpret_cast<uintptr_t>(rgb_sigma) & 15) == 0)) {
             const int nld = (int)((block / 4 + kWave - 1) / kWave);
             // persistent workgroups (as many as fit the LDS of the chip): every wave walks several rays, which is what the
             // request-ahead pipeline needs
             // one-wave workgroups: the LDS footprint is per wave (block + weights), so 64-thread workgroups pack the CU's 160 KB
             // with as many waves as fit (7 at 96 x 53) instead of one 4-wave workgroup
-            static const int mode = getenv("IDE3D_COMPOSITE_MODE") ? atoi(getenv("IDE3D_COMPOSITE_MODE")) : 0;
+            const int mode = knobs().composite_mode;
             const int wpb = (mode == 1 || mode == 3) ? 4 : 1;
             const size_t lds_w = lds / 4 * wpb;
             int64_t pgrid = (mode >= 2) ? (int64_t)kNumCU * ((160 * 1024) / (int64_t)lds_w) : cdiv64(rays, wpb);

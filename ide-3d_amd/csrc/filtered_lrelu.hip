@@ -13,6 +13,7 @@
 // filtered_lrelu.py:215-216).  The intermediate (up^2 larger) never touches HBM: traffic = in + out
 // (+ signs).  Non-separable filters run the same passes with 2-D tap loops.
 #include "common.h"
+#include "knobs.h"
 #include <stdlib.h>
 
 namespace ide3d {
@@ -412,33 +413,29 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
     }
     __syncthreads();
 
-    // ---- P4: vertical down-FIR -> global.  Thread item = (2 output rows, 4 columns): window of DOWN + FDT rows. ----
+    // ---- P4: vertical down-FIR -> global.  Thread item = (1 output row, 4 columns): window of FDT rows.  (Rounds 2-5: 2 rows per item
+    // = 128 items for 256 threads — half the lanes idle through a quarter of the tile's multiply-adds.) ----
     {
         T* yp = (T*)p.y + n * p.y_stride[0] + c * p.y_stride[1];
-        constexpr int WIN = DOWN + FDT;
-        for (int i = tid; i < (K::TOH / 2) * (K::TOW / 4); i += 256) {
-            const int o2 = (i / (K::TOW / 4)) * 2, o4 = (i % (K::TOW / 4)) * 4;
-            float4 w[WIN];
+        static_assert(K::TOH * (K::TOW / 4) == 256, "one item per thread");
+        const int o1 = tid / (K::TOW / 4), o4 = (tid % (K::TOW / 4)) * 4;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < WIN; ++k)
-                w[k] = (o2 * DOWN + k < K::ZH) ? *reinterpret_cast<const float4*>(s_d + (o2 * DOWN + k) * K::TOW + o4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < FDT; ++k) {
-                    a[0] += w[e * DOWN + k].x * fd[k]; a[1] += w[e * DOWN + k].y * fd[k];
-                    a[2] += w[e * DOWN + k].z * fd[k]; a[3] += w[e * DOWN + k].w * fd[k];
+        for (int k = 0; k < FDT; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(s_d + (o1 * DOWN + k) * K::TOW + o4);          // (o1 * DOWN + k <= (TOH - 1) DOWN + FDT - 1 = ZH - 1)
+            a[0] += w.x * fd[k]; a[1] += w.y * fd[k]; a[2] += w.z * fd[k]; a[3] += w.w * fd[k];
+        }
+        const int oy = oy0 + o1, ox = ox0 + o4;
+        if (oy < p.out_h) {
+            T* yr = yp + oy * p.y_stride[2] + ox * p.y_stride[3];
+            bool done = false;
+            if constexpr (sizeof(T) == 4) {
+                if (ox + 3 < p.out_w && p.y_stride[3] == 1 && ((reinterpret_cast<uintptr_t>(yr) & 15) == 0)) {
+                    *reinterpret_cast<float4*>(yr) = make_float4(a[0], a[1], a[2], a[3]);
+                    done = true;
                 }
-                const int oy = oy0 + o2 + e, ox = ox0 + o4;
-                if (oy >= p.out_h) continue;
-                T* yr = yp + oy * p.y_stride[2] + ox * p.y_stride[3];
-                if constexpr (sizeof(T) == 4) {
-                    if (ox + 3 < p.out_w && p.y_stride[3] == 1 && ((reinterpret_cast<uintptr_t>(yr) & 15) == 0)) {
-                        *reinterpret_cast<float4*>(yr) = make_float4(a[0], a[1], a[2], a[3]);
-                        continue;
-                    }
-                }
+            }
+            if (!done) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (ox + j < p.out_w) Elem<T>::st(yr + j * p.y_stride[3], a[j]);
             }
@@ -462,7 +459,7 @@ static int launch_flr_sep(const ide3d_filtered_lrelu_params& p, hipStream_t st) 
 // Returns 1 when a specialised instance ran, 0 when none matches (the generic kernel then takes the call), < 0 on error.
 template <class T>
 static int try_flr_sep(const ide3d_filtered_lrelu_params& p, hipStream_t st) {
-    static const bool off = getenv("IDE3D_FLR_GENERIC") != nullptr;
+    const bool off = knobs().flr_generic;
     if (off || p.fu_h != 0 || p.fd_h != 0) return 0;                // separable filters only
 #define IDE3D_FLS(U, D, FU, FD) \
     if (p.up == U && p.down == D && p.fu_w == FU && p.fd_w == FD) { const int rc = launch_flr_sep<T, U, D, FU, FD>(p, st); return rc ? rc : 1; }

@@ -34,6 +34,7 @@
 // Bound: fp32 MFMA (157.3 TFLOP/s peak); LDS and L2 traffic stay below 10 B/clk/CU.  The split-bf16 loop is bound by the bf16 MFMA
 // (2.5 PFLOP/s / 6 products) and, below 16 x 16-pixel tiles, by its weight stream.
 #include "common.h"
+#include "knobs.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -610,10 +611,7 @@ struct SpCfg {
     static constexpr int NLOAD = 4;                                  // waves that stage (patch: waves 0-3; weights: the last four)
     static constexpr int KC = 16;
     // patch with halo: the transposed taps read offsets 0 and 1 only (input i - 1 and i), so their patch has ONE halo row / column
-#ifndef IDE3D_TA_HALO
-#define IDE3D_TA_HALO 1
-#endif
-    static constexpr int HALO = (MODE == MODE_TCONV3A) ? IDE3D_TA_HALO : 2;
+    static constexpr int HALO = (MODE == MODE_TCONV3A) ? 1 : 2;
     static constexpr int HP = PH + HALO, HW = PW + HALO, NSLOT = HP * HW;
     static constexpr int NS = PARTS * (PARTS + 1) / 2;               // products per k step
     static constexpr int W_UNITS = 3 * PARTS * 2 * BM;               // 16-byte units per weight stage (one kernel row)
@@ -643,13 +641,8 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PAR
         // residuals a - float(hi.lo), b - float(hi.hi) in ONE instruction each: v_fma_mix_f32 reads the fp16 half directly (hipcc emits
         // v_cvt_f32_f16 [+ SDWA] and v_sub_f32 for the plain expression: 6 instead of 4 VALU per pair in the issue-bound patch staging)
         f32x2 r;
-#ifdef IDE3D_F16_NO_FMA_MIX
-        const f16x2 h = __builtin_bit_cast(f16x2, hi);
-        r = f32x2{a - (float)h.x, b - (float)h.y};
-#else
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(hi), "v"(a));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(hi), "v"(b));
-#endif
         out[0] = hi; out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     } else {
 #pragma unroll
@@ -662,9 +655,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[PAR
 }
 template <int F16>
 __device__ __forceinline__ f32x16 sp_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-#ifdef IDE3D_F16_BF16MFMA        // timing experiment only (wrong results): the bf16 instruction on the fp16 pieces
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -798,14 +788,8 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
         f16_scale(mm * xm, xs, xus);
     }
     const bool stages_patch = (NWV == 4) || wid < 4;
-#ifdef IDE3D_SP_DBG
-    const int c_begin_dbg = split * g.chunks_per_split; bool patch_done_dbg = false;
-#endif
     auto fetch_patch = [&](int c) {
         if (!stages_patch) return;
-#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 6)            // ... the patch is staged once (2) / loaded once and committed every chunk (4)
-        if (c > c_begin_dbg) return;
-#endif
         const int ci0 = c * K::KC + wid * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -817,13 +801,6 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     };
     auto commit_patch = [&](int buf) {
         if (!stages_patch) return;
-#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 10)           // (8: loaded every chunk, committed once)
-        if (buf != 0 || patch_done_dbg) {
-            for (int r = 0; r < K::NXR; ++r) asm volatile("" :: "v"(xreg[r][0]), "v"(xreg[r][1]), "v"(xreg[r][2]), "v"(xreg[r][3]));      // (the loads stay alive)
-            return;
-        }
-        patch_done_dbg = true;
-#endif
         unsigned char* const dst = reinterpret_cast<unsigned char*>(s_x + buf * K::X_UNITS) + ((wid >> 1) * K::NSLOT) * 16 + (wid & 1) * 8;
         // f16x3: the image scale joins the styles HERE, where the (scalar) style loads are waited for anyway — multiplied in fetch_patch it
         // forces `s_waitcnt lgkmcnt(0)` right behind the loads, in the middle of the hand-counted operand-read pipeline (scalar loads and
@@ -856,9 +833,6 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
     constexpr int W_EARLY = (NWV == 8) ? (W_COL * 5 + 8) / 9 : W_COL;
     auto fetch_weights = [&](int stage, int buf, bool late = false) {
         const u32x4* src = wsrc + (int64_t)stage * K::W_UNITS;
-#if defined(IDE3D_SP_DBG) && (IDE3D_SP_DBG & 1)            // timing experiments only (wrong results): the weights are fetched once
-        if (stage > c_begin_dbg * 3 + 1) return;
-#endif
         if (NWV == 4 && late) return;
         if (NWV == 8 && (late != (wid < 4))) return;
         const int m0 = late ? W_EARLY : 0, m1 = late ? W_COL : W_EARLY;
@@ -925,26 +899,21 @@ __device__ __forceinline__ void modconv_split_tile(const ide3d_modconv_params& p
             // Software pipeline over (tap, piece) groups: the A and B pieces q of tap kx are one group of MTW + NTW 16-byte reads;
             // group s + 1 is in flight while the products that group s completes - (qa, qb) with max(qa, qb) = q and
             // qa + qb < PARTS - multiply.  At most two groups (<= 12 reads) are outstanding: lgkmcnt is a 4-bit counter.
-            // AHEAD groups in flight (compile-time knob IDE3D_SP_AHEAD; default 1 = the round-2 pipeline).  Round 4 measured 2 (bf16x6; f16x3 with
+            // AHEAD groups in flight (SP_AHEAD = 1: the round-2 pipeline).  Round 4 measured 2 (bf16x6; f16x3 with
             // a third tap buffer): 338 vs 330 us at 128 -> 128 @256, 255 vs 251 at the transposed 256 -> 128, 218 vs 211 in f16x3 - with two
             // waves per SIMD the LDS latency is already covered, more reads in flight only delay the first product.  The operand registers of a tap are reused by the tap
             // two taps later (NBUF = 2) or three (NBUF = 3): group s + AHEAD may only be issued once every product of the tap it overwrites
             // has been ISSUED at least one group earlier, i.e. AHEAD <= (NBUF - 1) * PARTS - 1; and (AHEAD + 1) * GRP <= 15 reads outstanding.
             constexpr int GRP = K::MTW + K::NTW, NGRP = 3 * PARTS;
-#ifndef IDE3D_SP_AHEAD
-#define IDE3D_SP_AHEAD 1
-#endif
-            constexpr int NBUF = (PARTS == 2 && IDE3D_SP_AHEAD > 1) ? 3 : 2;
+            constexpr int SP_AHEAD = 1;
+            constexpr int NBUF = (PARTS == 2 && SP_AHEAD > 1) ? 3 : 2;
             constexpr int AHEAD_CAP = 15 / GRP - 1, AHEAD_SAFE = (NBUF - 1) * PARTS - 1;
-            constexpr int AHEAD = (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) < AHEAD_SAFE ? (IDE3D_SP_AHEAD < AHEAD_CAP ? IDE3D_SP_AHEAD : AHEAD_CAP) : AHEAD_SAFE;
+            constexpr int AHEAD = (SP_AHEAD < AHEAD_CAP ? SP_AHEAD : AHEAD_CAP) < AHEAD_SAFE ? (SP_AHEAD < AHEAD_CAP ? SP_AHEAD : AHEAD_CAP) : AHEAD_SAFE;
             static_assert(AHEAD >= 1 && (AHEAD + 1) * GRP <= 15, "lgkmcnt is a 4-bit counter");
             // All-class transposed form: the patch offset of tap (ky, kx) is ((ky == 2) ? 0 : 1, (kx == 2) ? 0 : 1), i.e. the taps kx = 0 and
             // kx = 1 of a kernel row multiply the SAME patch fragment: it is read once (slot 0; kx = 2 reads into slot 1), which takes a third
-            // of the patch reads out of the LDS-bound loop (IDE3D_TA_BREUSE=0: one read per tap, the round-2 form)
-#ifndef IDE3D_TA_BREUSE
-#define IDE3D_TA_BREUSE 1
-#endif
-            constexpr bool B_REUSE = (MODE == MODE_TCONV3A) && IDE3D_TA_BREUSE >= 1 && NBUF == 2;
+            // of the patch reads out of the LDS-bound loop
+            constexpr bool B_REUSE = (MODE == MODE_TCONV3A) && NBUF == 2;
             u32x4 av[NBUF][K::MTW][PARTS], bv[NBUF][K::NTW][PARTS];
             auto issue = [&](auto ss) {
                 constexpr int S = decltype(ss)::value, KX = S / PARTS, Q = S % PARTS, B = KX % NBUF, T = KY * 3 + KX;
@@ -1211,11 +1180,7 @@ head_resident_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int w
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 2)        // timing experiments only (wrong results): no activation loads
-                xr[B][c][e] = (float)(t + c + e);
-#else
                 xr[B][c][e] = *reinterpret_cast<const float*>(src + (c * 16 + e) * plane + x_lane);
-#endif
             }
     };
     // The accumulators start from the bias (rows m * 32 + 8 g + 4 half + 0..3 of register group g: one 16-byte LDS read), so the finish is
@@ -1253,11 +1218,7 @@ head_resident_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int w
                 for (int g = 0; g < MG; ++g)
 #pragma unroll
                     for (int q = 0; q < PARTS; ++q) af[g][q] = sa[q * 2 * K::ROWS + (m0 + g) * 32];
-#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 4)        // timing experiments only (wrong results): one product instead of PARTS (PARTS + 1) / 2
-                constexpr int NQA = 1;
-#else
                 constexpr int NQA = PARTS;
-#endif
 #pragma unroll
                 for (int qa = 0; qa < NQA; ++qa)
 #pragma unroll
@@ -1283,11 +1244,7 @@ head_resident_kernel(ide3d_modconv_params p, const u32x4* __restrict__ wp, int w
                         float v = acc[m][r];
                         if (!UNIT) v *= e_gain;
                         v = __builtin_amdgcn_fmed3f(v, -e_clamp, e_clamp);
-#if defined(IDE3D_HEAD_DBG) && (IDE3D_HEAD_DBG & 1)        // ... no stores (one that never happens keeps the values alive)
-                        if (v == 1.2345e-30f) *reinterpret_cast<float*>(dst + row_u * plane + y_lane) = v;
-#else
                         *reinterpret_cast<float*>(dst + row_u * plane + y_lane) = v;
-#endif
                         if (want_amax) amax_acc(amax, v);
                     }
                 }
@@ -1741,22 +1698,17 @@ struct ConvPlan {
 // transposed kernel off, IDE3D_MODCONV_TILE forces a pixel tile (0..3), IDE3D_MODCONV_DEBUG = 1 drops the staging after
 // the first chunk (timing experiments; wrong results).
 struct McEnv { bool no_flat, no_allcls; int tile, debug, ta_rows; };
-static const McEnv& mc_env() {
-    static const McEnv e = {getenv("IDE3D_MODCONV_NO_FLAT") != nullptr, getenv("IDE3D_MODCONV_NO_TCONV3A") != nullptr,
-                            getenv("IDE3D_MODCONV_TILE") ? atoi(getenv("IDE3D_MODCONV_TILE")) : -1,
-                            getenv("IDE3D_MODCONV_DEBUG") ? atoi(getenv("IDE3D_MODCONV_DEBUG")) : 0,
-                            getenv("IDE3D_MODCONV_TA_ROWS") ? atoi(getenv("IDE3D_MODCONV_TA_ROWS")) : 0};
+static const McEnv& mc_env() {          // (knobs.h: read once)
+    static const McEnv e = {knobs().mc_no_flat, knobs().mc_no_allcls, knobs().mc_tile, knobs().mc_debug, knobs().mc_ta_rows};
     return e;
 }
 
 // Experiment switches of plan_conv (A/B runs of scripts/micro/: each is the "before" of a plan rule and is documented where the rule is),
 // read once.  IDE3D_MODCONV_NO_STRIP alone is read per call: tests/test_gpu_conv_arith.py flips it inside one process.
 struct PlanKnobs { bool ta_bm64, head_bm128, ta_kc8, no_smallmap, ta_old, sp_oldplan, no_ph32, no_w8split, no_one_round; int sp_modes; };
-static const PlanKnobs& plan_knobs() {
-    auto on = [](const char* name) { return getenv(name) != nullptr; };
-    static const PlanKnobs k = {on("IDE3D_MODCONV_TA_BM64"), on("IDE3D_MODCONV_HEAD_BM128"), on("IDE3D_MODCONV_TA_KC8"), on("IDE3D_MODCONV_NO_SMALLMAP"),
-                                on("IDE3D_MODCONV_TA_OLD"), on("IDE3D_MODCONV_SP_OLDPLAN"), on("IDE3D_MODCONV_NO_PH32"), on("IDE3D_MODCONV_NO_W8SPLIT"),
-                                on("IDE3D_MODCONV_NO_ONE_ROUND"), getenv("IDE3D_MODCONV_SP_MODES") ? atoi(getenv("IDE3D_MODCONV_SP_MODES")) : 3};
+static const PlanKnobs& plan_knobs() {          // (knobs.h: read once)
+    const Knobs& e = knobs();
+    static const PlanKnobs k = {e.ta_bm64, e.head_bm128, e.ta_kc8, e.no_smallmap, e.ta_old, e.sp_oldplan, e.no_ph32, e.no_w8split, e.no_one_round, e.sp_modes};
     return k;
 }
 
@@ -1779,13 +1731,7 @@ static int g_conv_arith = 0;
 static int conv_arith_default() {
     if (g_conv_arith) return g_conv_arith;
     static const int env = [] {
-        const char* e = getenv("IDE3D_CONV_ARITH");
-        if (!e) return 6;
-        if (!strcmp(e, "fp32") || !strcmp(e, "1")) return 1;
-        if (!strcmp(e, "bf16x3") || !strcmp(e, "3")) return 3;
-        if (!strcmp(e, "bf16x6") || !strcmp(e, "6")) return 6;
-        if (!strcmp(e, "f16x3") || !strcmp(e, "16")) return 16;
-        return 6;
+        return knobs().conv_arith;          // IDE3D_CONV_ARITH (knobs.h)
     }();
     return env;
 }
@@ -1798,7 +1744,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.mode = (p.mode == 2) ? MODE_TCONV3 : (p.mode == 1) ? MODE_CONV3S2 : (p.k == 1 ? MODE_CONV1 : MODE_CONV3);
     // all-class form from 4 x 4 maps on (round 3: the per-class form took 65 / 78 us for the 0.3-GFLOP layers at 4^2 / 8^2; 962 -> 974-981
     // frames/s; IDE3D_MODCONV_ALLCLS_MIN=12 restores the old threshold)
-    static const int allcls_min = getenv("IDE3D_MODCONV_ALLCLS_MIN") ? atoi(getenv("IDE3D_MODCONV_ALLCLS_MIN")) : 4;
+    const int allcls_min = knobs().allcls_min;
     const bool allcls = (pl.mode == MODE_TCONV3) && mc_bm(p.cout) >= 64 && p.h >= allcls_min && p.w_ >= allcls_min && !mc_env().no_allcls;
     if (allcls) pl.mode = MODE_TCONV3A;
     pl.bm = mc_bm(p.cout);
@@ -1806,7 +1752,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         // all-class transposed conv with too few 128-row blocks to fill the 768 resident slots (3 per CU): 64-row blocks double
         // the block count (512 -> 512 in@32: 432 -> 864 blocks, measured +5 %)
         const int64_t blocks128 = (int64_t)cdiv(p.cout, 128) * cdiv(p.h + 1, 4) * cdiv(p.w_ + 1, 16) * p.n;
-        static const bool old_plan = getenv("IDE3D_MODCONV_TA_OLD") != nullptr;
+        const bool old_plan = knobs().ta_old;
         if ((blocks128 < 3 * kNumCU * 3 / 4 && !old_plan) || mc_env().ta_rows == 64 || plan_knobs().ta_bm64) pl.bm = 64;
     }
     // 1x1 heads with cout = 192 (96 + 96 tri-plane channels): three 64-row blocks instead of 128 + 64 rows padded to 128
@@ -1825,7 +1771,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     pl.parts = 0; pl.f16 = 0; pl.aux_floats = 0; pl.strip_off = 0; pl.strip_floats = 0; pl.pair = 0;
     int want_split = 0;                                         // split-K chosen together with the form (0 = by block count below)
     bool one_round = false;                                     // transposed 8-wave form chosen for whole rounds on the strip plan's grid: no split-K
-    static const int split_min = getenv("IDE3D_MODCONV_SPLIT_MIN") ? atoi(getenv("IDE3D_MODCONV_SPLIT_MIN")) : 512;      // fewer workgroups than this: split-K
+    const int split_min = knobs().split_min;      // fewer workgroups than this: split-K
     // class grids
     int gh[4], gw[4];
     const int ncls = (pl.mode == MODE_TCONV3) ? 4 : 1;
@@ -1875,14 +1821,14 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     // (3x3 layers with fewer than 3 K chunks stay on the fp32 loop: prologue + epilogue dominate)
     // (transposed layers from 32 input channels = 2 K chunks on: 32 -> 128 in@128 78.6 -> 60.5 us on the 8-wave strip-plan form; round 3's 81 vs 76
     // the other way round was the 4-wave (h + 1) x (w + 1) form)
-    static const int sp_min_cin = getenv("IDE3D_MODCONV_SP_MINCIN") ? atoi(getenv("IDE3D_MODCONV_SP_MINCIN")) : 0;
+    const int sp_min_cin = knobs().sp_min_cin;
     const int min_cin = sp_min_cin ? sp_min_cin : (pl.mode == MODE_TCONV3A ? 32 : 33);
     if (arith != 1 && (pl.mode == MODE_CONV3 || pl.mode == MODE_TCONV3A) && !p.w_batch_stride && pl.big != 0 && p.cin >= min_cin &&
         (pl.tile == 0 || pl.tile == 3 || pl.tile == 4 || pl.tile == 6 || pl.tile == 7) && !ta_kc8 &&
         (plan_knobs().sp_modes & (pl.mode == MODE_CONV3 ? 1 : 2))) {
         pl.parts = (arith == 3 || arith == 16) ? 2 : 3;
         pl.f16 = (arith == 16) ? 1 : 0;
-        static const int sp_rows = getenv("IDE3D_MODCONV_SP_ROWS") ? atoi(getenv("IDE3D_MODCONV_SP_ROWS")) : 0;
+        const int sp_rows = knobs().sp_rows;
         // Exclusive residency (round 4): one workgroup per CU, so the forms that put TWO of their own waves on a SIMD (8 waves) are chosen
         // wherever the launch still has >= 2 workgroups per CU to run through; measured per layer, bf16x6 / f16x3 us at batch 4:
         //   64 -> 64 @512: 16 x 16 px x 64 rows, 8 waves 431 / 343 (8 x 16, 4 waves with the whole SIMD claimed: 537 / 457)
@@ -1905,7 +1851,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 // on the h x w grid of a strip plan (below) the 8-wave form may come out at whole rounds of ONE workgroup per CU where the (h + 1) x
                 // (w + 1) grid did not: 512 -> 256 in@64 = 256 workgroups of 8 x 16 positions x 128 rows, no split-K: 241 -> 211 us (f16x3 181 -> 149)
                 // against 512 four-wave workgroups of 4 x 16; 512 -> 512 in@32 (64 rows): 149 -> 141 against 256 two-team workgroups
-                const bool strip_ok = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
+                const bool strip_ok = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !knob_live("IDE3D_MODCONV_NO_STRIP") && !plan_knobs().no_one_round;
                 const int64_t b8s = (int64_t)pl.mblocks * cdiv(p.h, 8) * cdiv(p.w_, 16) * p.n, b4s = (int64_t)pl.mblocks * cdiv(p.h, 4) * cdiv(p.w_, 16) * p.n;
                 const int64_t b16s = (int64_t)pl.mblocks * cdiv(p.h, 16) * cdiv(p.w_, 16) * p.n;
                 auto rounds = [](int64_t blocks) { return (blocks + kNumCU - 1) / kNumCU; };
@@ -1917,7 +1863,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
                 else if (b16 >= 2 * kNumCU) pl.tile = 7;
                 // whole rounds of ONE 8-wave workgroup of 16 x 16 positions per CU on the strip grid (128 -> 64 in@256 at batch 1: 256 workgroups) against
                 // four-wave workgroups of 4 x 16 (a quarter of the work at ~1.15 x the time per unit; no team pairs with an odd block count)
-                else if (strip_ok && (pl.mblocks & 1) && b16s >= kNumCU && rounds(b16s) * 400 <= rounds(b4s) * 115 && !getenv("IDE3D_MODCONV_NO_R16")) { pl.tile = 7; one_round = true; }
+                else if (strip_ok && (pl.mblocks & 1) && b16s >= kNumCU && rounds(b16s) * 400 <= rounds(b4s) * 115 && !knob_live("IDE3D_MODCONV_NO_R16")) { pl.tile = 7; one_round = true; }
                 else if (strip_ok && (pl.mblocks & 1) == 0 && b8s >= kNumCU && rounds(b8s) * 100 <= rounds(b4s / 2) * 105) { pl.tile = 6; one_round = true; }
                 else if (p.h <= 16 && p.w_ <= 16 && (pl.mblocks & 1)) pl.tile = 6;       // 4^2 .. 16^2 maps with an odd block count (no team pairs): 8 x 16 positions, 8 waves: 99 / 45 / 24 us at in@16 / 8 / 4 (4 waves alone on a CU: 115 / 47 / 31; two 4-wave teams: 92 / 45 / 24)
             }
@@ -1932,7 +1878,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
             if (sp_rows == 8) pl.tile = 6;
             if (sp_rows == 16 && pl.big == 2) pl.tile = 7;
         }
-        static const int sp_maxlds = getenv("IDE3D_MODCONV_SP_MAXLDS") ? atoi(getenv("IDE3D_MODCONV_SP_MAXLDS")) : 0;
+        const int sp_maxlds = knobs().sp_maxlds;
         const int ph = (pl.tile == 4) ? 4 : (pl.tile == 0 || pl.tile == 6) ? 8 : (pl.tile == 12) ? 32 : 16;
         const int lds = 2 * 16 * (3 * pl.parts * 2 * pl.bm + pl.parts * 2 * (ph + 2) * 18);
         if (sp_maxlds && lds > sp_maxlds) pl.parts = 0;
@@ -1941,9 +1887,9 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
         // to fill in behind: 256 -> 128 in@128 at batch 4; 512 -> 256 in@64 (128 per parity: 215 -> 237 us) keeps the 8 x 16 form; 128-row blocks
         // only (see the kernel).  IDE3D_MODCONV_PAIR (read per call: the tests flip it): 0 = never, 2 = wherever the form exists.
         if (pl.parts && pl.mode == MODE_TCONV3A && kSpExclusive && !sp_rows && !sp_maxlds) {
-            const char* pe = getenv("IDE3D_MODCONV_PAIR");
+            const char* pe = knob_live_str("IDE3D_MODCONV_PAIR");
             const int pair_knob = pe ? atoi(pe) : 1;
-            const bool plain = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP");
+            const bool plain = !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !knob_live("IDE3D_MODCONV_NO_STRIP");
             const int64_t per_parity = (int64_t)pl.mblocks * cdiv(p.h, pl.big == 1 ? 16 : 32) * cdiv(p.w_, 16) * p.n;
             if (plain && pair_knob && (pair_knob == 2 || (pl.big == 1 && per_parity >= kNumCU && p.cin >= 64))) {
                 pl.pair = 1; pl.tile = (pl.big == 1) ? 7 : 12; one_round = true;
@@ -1966,7 +1912,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     // layers (demodulation only: noise / bias / activation follow the FIR).  IDE3D_MODCONV_NO_STRIP = the (h + 1) x (w + 1) grid everywhere.
     // Shared weights only: the strip's pack / compute kernels read ONE weight tensor (per-image weights stay on the (h + 1) x (w + 1) grid).
     pl.strip = 0;
-    if (pl.mode == MODE_TCONV3A && !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !getenv("IDE3D_MODCONV_NO_STRIP")) {
+    if (pl.mode == MODE_TCONV3A && !p.w_batch_stride && !p.noise && !p.bias && p.act == 1 && p.gain == 1.f && p.clamp < 0.f && !knob_live("IDE3D_MODCONV_NO_STRIP")) {
         const int ph = PHv[pl.tile], pw = PWv[pl.tile];
         const int64_t t_full = (int64_t)cdiv(p.h + 1, ph) * cdiv(p.w_ + 1, pw), t_main = (int64_t)cdiv(p.h, ph) * cdiv(p.w_, pw);
         const int64_t groups = cdiv(p.n, TIv[pl.tile]);
@@ -1995,7 +1941,7 @@ static void plan_conv(const ide3d_modconv_params& p, ConvPlan& pl, int arith) {
     }
     if (one_round) want_split = 1;
     if (want_split > 0) split = want_split < pl.cchunks ? want_split : pl.cchunks;
-    static const int force_split = getenv("IDE3D_MODCONV_SPLITK") ? atoi(getenv("IDE3D_MODCONV_SPLITK")) : 0;   // experiments
+    const int force_split = knobs().force_split;   // experiments
     if (force_split > 0 && !pl.strip) split = force_split < pl.cchunks ? force_split : pl.cchunks;
     g.chunks_per_split = cdiv(pl.cchunks, split);
     g.split_k = cdiv(pl.cchunks, g.chunks_per_split);
@@ -2036,8 +1982,8 @@ constexpr int kSpW8Default = kSpExclusive ? 2 : 0;
 // on the 16 x 16 tiles as well; IDE3D_SP_NO_TEAMS = no two-team workgroups.
 struct SpForm { int waves; bool teams; };
 static SpForm sp_form(const ConvPlan& pl) {
-    static const int w8 = getenv("IDE3D_SP_W8") ? atoi(getenv("IDE3D_SP_W8")) : kSpW8Default;
-    static const bool no_teams = getenv("IDE3D_SP_NO_TEAMS") != nullptr, no8 = getenv("IDE3D_MODCONV_SP_W4") != nullptr;
+    const int w8 = knobs().sp_w8 >= 0 ? knobs().sp_w8 : kSpW8Default;
+    const bool no_teams = knobs().sp_no_teams, no8 = knobs().sp_w4;
     const bool conv3 = (pl.mode == MODE_CONV3);
     if (pl.pair) return {8, false};
     // 64-row blocks, even block count: two teams per workgroup (128-row blocks: LDS does not fit twice in bf16x6, and in f16x3 the teams measured 233 vs 217 us at 512 -> 256 in@64)
@@ -2071,7 +2017,7 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
     }
     else if (pl.tile == 0 || pl.tile == 6) {
         // 3x3: one weight buffer, two workgroups per CU (measured 338 vs 355 us at 512 -> 512 @64, bf16x6); IDE3D_MODCONV_SP_WBUF2 = old form
-        static const bool one_wbuf = getenv("IDE3D_MODCONV_SP_WBUF2") == nullptr && !kSpExclusive;
+        const bool one_wbuf = !knobs().sp_wbuf2 && !kSpExclusive;
         if (form.waves == 8) IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 8, F16>), dim3(nblocks), 512, 0, st, p, wu, partial, g, ru);
         else if (one_wbuf && MODE == MODE_CONV3) IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE_CONV3, BIG, 8, PARTS, 1, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
         else IDE3D_EXCL_LAUNCH((modconv_split_kernel<MODE, BIG, 8, PARTS, 2, 4, F16>), dim3(nblocks), 256, 0, st, p, wu, partial, g, ru);
@@ -2090,7 +2036,7 @@ static void launch_split(const ide3d_modconv_params& p, const ConvPlan& pl, cons
 
 // per-image 1x1 convolution without modulation / noise, linear, <= 32 or 161..192 outputs: the dual heads
 static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
-    static const bool off = getenv("IDE3D_MODCONV_HEAD_FP32") != nullptr;
+    const bool off = ide3d::knobs().head_fp32;
     return !off && arith != 1 && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 &&
            (p.cout <= 32 || (p.cout > 160 && p.cout <= 192)) && p.cin >= 32 &&
            (int64_t)p.n * ide3d::cdiv64((int64_t)p.h * p.w_, 32 * ide3d::head_waves(p.cout <= 32 ? 1 : 6)) >= ide3d::kNumCU;     // fewer workgroups: the serial K loop of a workgroup is exposed
@@ -2099,13 +2045,13 @@ static bool head_split_applies(const ide3d_modconv_params& p, int arith) {
 
 // per-image linear 1x1 convolution on a small map: one launch of fp32 FMAs (head_small_kernel) in every arithmetic
 static bool head_small_applies(const ide3d_modconv_params& p) {
-    static const bool no_small = getenv("IDE3D_HEAD_NO_SMALL") != nullptr;
+    const bool no_small = ide3d::knobs().head_no_small;
     return !no_small && p.k == 1 && p.mode == 0 && p.w_batch_stride > 0 && !p.styles && !p.dcoefs && !p.noise && p.act == 1 && (int64_t)p.h * p.w_ <= 256 &&
            p.y_pitch == 0 && p.n <= 65535;
 }
 // resident-weights form of the split heads: whole K in LDS (K = 64 / 128 at <= 32 rows, K = 128 at 192 rows), >= 2 tiles of 32 pixels per wave
 static bool head_resident_applies(const ide3d_modconv_params& p) {
-    static const bool no_resident = getenv("IDE3D_HEAD_NO_RESIDENT") != nullptr;
+    const bool no_resident = ide3d::knobs().head_no_resident;
     const int mt = p.cout <= 32 ? 1 : 6, cchunks = ide3d::cdiv(p.cin, 16);
     const int hw = p.h * p.w_, wgs_img = ide3d::kNumCU / p.n, tiles32 = hw / 32;
     return !no_resident && ide3d::kSpExclusive && p.cin % 16 == 0 && hw % 32 == 0 && wgs_img >= 1 && p.y_pitch == 0 &&
@@ -2316,26 +2262,11 @@ extern "C" int ide3d_debug_mc(unsigned long long* host) {
 namespace ide3d {
 const char* modconv_build_flags() {
     return ""
-#ifdef IDE3D_SP_DBG
-        "!IDE3D_SP_DBG=" IDE3D_STR(IDE3D_SP_DBG) " "
-#endif
-#ifdef IDE3D_HEAD_DBG
-        "!IDE3D_HEAD_DBG=" IDE3D_STR(IDE3D_HEAD_DBG) " "
-#endif
-#ifdef IDE3D_F16_BF16MFMA
-        "!IDE3D_F16_BF16MFMA "
-#endif
 #ifdef IDE3D_SP_SHARED_SIMD
         "!IDE3D_SP_SHARED_SIMD "
 #endif
-#ifdef IDE3D_F16_NO_FMA_MIX
-        "IDE3D_F16_NO_FMA_MIX "
-#endif
 #ifdef IDE3D_MC_TRACE
         "IDE3D_MC_TRACE "
-#endif
-#if IDE3D_SP_AHEAD != 1
-        "IDE3D_SP_AHEAD=" IDE3D_STR(IDE3D_SP_AHEAD) " "
 #endif
         ;
 }

@@ -18,6 +18,7 @@
 // Index math is bit-exact w.r.t. ATen grid_sampler_unnormalize (align_corners=False):
 //   u = ((c + 1) * size - 1) / 2 evaluated add, mul, sub, mul(0.5) in fp32 without contraction.
 #include "common.h"
+#include "knobs.h"
 #include "triplane_tap.h"
 
 namespace ide3d {
@@ -368,7 +369,7 @@ extern "C" int ide3d_triplane_sample_rays(const float* planes, const int64_t pla
     IDE3D_CHECK_ARG(n > 0 && C > 0 && H > 0 && W > 0 && m >= 0, "triplane_sample_rays: bad shape");
     IDE3D_CHECK_ARG(rays_h > 0 && rays_w > 0 && steps > 0 && (int64_t)rays_h * rays_w * steps == m,
                     "triplane_sample_rays: m must equal rays_h * rays_w * steps");
-    static const bool no_tile = getenv("IDE3D_GATHER_NO_TILE") != nullptr;
+    const bool no_tile = knobs().gather_no_tile;
     const bool aligned = ((reinterpret_cast<uintptr_t>(planes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                          (plane_stride[0] % 4 == 0) && (plane_stride[2] % 4 == 0) && (plane_stride[3] % 4 == 0);
     if (!no_tile && aligned &&

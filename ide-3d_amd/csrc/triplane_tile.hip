@@ -28,6 +28,7 @@
 //
 // Arithmetic (tap indices, weights, blend order) is identical to triplane.hip: results are bit-equal (tests).
 #include "common.h"
+#include "knobs.h"
 #include "triplane_tap.h"
 
 namespace ide3d {
@@ -39,10 +40,6 @@ __device__ unsigned long long g_tt_dbg[256];
 #define IDE3D_TS(k) if (blockIdx.x == 300 && threadIdx.x == 0) g_tt_dbg[ch * 8 + (k)] = __builtin_readcyclecounter();
 #else
 #define IDE3D_TS(k)
-#endif
-
-#ifdef IDE3D_PC_EXP
-#define IDE3D_PC_EXP_DEFINED_EARLY IDE3D_PC_EXP
 #endif
 
 namespace {
@@ -180,9 +177,6 @@ template <bool STAGED>
 __device__ __forceinline__ void load_lines(const TileArgs& p, const unsigned char* s_lines, __amdgpu_buffer_rsrc_t rsrc,
                                            unsigned pitch, unsigned e, unsigned ch_bytes, f32x4_t (&v)[4]) {
     if (STAGED) {
-#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 4)
-        e = (e & ~128u) | ((((unsigned)threadIdx.x >> 4) & 1u) << 7);        // slot >> 1 picks the bank half
-#endif
         const unsigned char* l0 = s_lines + (e | ch_bytes);
         const unsigned char* l1 = l0 + pitch;
         v[0] = *reinterpret_cast<const f32x4_t*>(l0);
@@ -235,9 +229,6 @@ __device__ __forceinline__ void blend_chunk(const TileArgs& p, const unsigned ch
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const size_t d = (size_t)((unsigned)(r >> 2) * (unsigned)p.rays_w + (unsigned)(r & 3) * 2u) * (unsigned)p.steps * TT_C;
-#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 8)
-        if (res[r][0] == 1.2345e-30f)
-#endif
         __builtin_nontemporal_store(res[r], reinterpret_cast<f32x4_t*>(o_lane + d));
     }
 }
@@ -354,13 +345,6 @@ __device__ __forceinline__ void stage_dma(const TileArgs& p, __amdgpu_buffer_rsr
 template <int NSEG>
 __device__ __forceinline__ void stage_commit_n(const Region& R, unsigned char* s_lines, int wid, int lane, int ns, const u32x4 (&v)[NSEG]) {
     unsigned char* dst = s_lines + (R.base + (unsigned)wid * 8u) * TT_LINE + (unsigned)lane * 16u;
-#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 2)
-    unsigned keep = 0;
-#pragma unroll
-    for (int j = 0; j < NSEG; ++j) if (j < ns) keep ^= v[j][0] ^ v[j][1] ^ v[j][2] ^ v[j][3];
-    if (keep == 0x12345678u && ns > 100) *reinterpret_cast<unsigned*>(dst) = keep;       // never happens: keeps the loads alive
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < NSEG; ++j)
         if (j < ns) *reinterpret_cast<u32x4*>(dst + j * 32 * TT_LINE) = v[j];
@@ -387,13 +371,6 @@ __device__ __forceinline__ unsigned make_regions(unsigned lo0, unsigned lo1, uns
     };
     const unsigned l0 = lines_of(R[0], TT_SEGS_A), l1 = lines_of(R[1], TT_SEGS_B), l2 = lines_of(R[2], TT_SEGS_A);
     unsigned mask;
-#if defined(IDE3D_PC_EXP_DEFINED_EARLY) && (IDE3D_PC_EXP_DEFINED_EARLY & 1)
-    if (l0 <= cap && l1 <= cap && l2 <= cap) {
-        R[0].staged = R[1].staged = R[2].staged = true;
-        R[0].base = 0; R[1].base = (l0 + l1 <= cap) ? l0 : cap - l1; R[2].base = (l0 + l1 + l2 <= cap) ? l0 + l1 : cap - l2;
-        return 7u;
-    }
-#endif
     if (l0 + l1 + l2 <= cap) mask = 7u;
     else {
         const unsigned s01 = l0 + l1, s02 = l0 + l2, s12 = l1 + l2;
@@ -606,34 +583,11 @@ triplane_sample_tile_kernel(const TileArgs p) {
 // `s_barrier` per iteration hands everything over.  Same arithmetic, same tap table, same blend code as above: bit-equal results.
 // (First attempt, measured: stager waves doing T + F in sequence beside four blenders = 7.0k cycles per chunk for the stager against
 // 5.3k for the blender, 80.5 us — the same as the 4-wave kernel; the split below takes the fetch off the tap waves' critical path.)
-// IDE3D_PC_EXP (timing experiments only, WRONG RESULTS; `make EXTRA=-DIDE3D_PC_EXP=n`, listed by ide3d_build_flags() with a '!'):
-//   1: every in-plane region counts as staged whatever the capacity (bases clamped into the buffer: regions overlap)
-//   2: the F waves skip their LDS writes          4: the blend reads lines whose bank halves alternate by slot (no bank conflicts)
-//   8: no output stores
-#ifndef IDE3D_PC_EXP
-#define IDE3D_PC_EXP 0
-#endif
-#ifndef IDE3D_PC_RWAVE
-#define IDE3D_PC_RWAVE 0                      // 1: wave 7 is a dedicated region builder R (F = waves 4-6) — measured 1-2 us SLOWER than 0 (T wave 0 builds the table beside its taps): R alone needs a whole iteration for the table chain and is last at the barrier instead
-#endif
-#ifndef IDE3D_PC_VECTABLE
-#define IDE3D_PC_VECTABLE 1                   // 1: the region table's per-plane arithmetic on lanes 0-2 (build_region_table); 0: all scalar (round 3)
-#endif
-#ifndef IDE3D_PC_DMA
-#define IDE3D_PC_DMA 1                        // 1: the F waves fill the line buffers by LDS-DMA (stage_dma) instead of loads + ds_write
-#endif
-#ifndef IDE3D_PC_PRIO_T
-#define IDE3D_PC_PRIO_T 0                     // s_setprio per role (experiments)
-#endif
-#ifndef IDE3D_PC_PRIO_T0
-#define IDE3D_PC_PRIO_T0 0
-#endif
-#ifndef IDE3D_PC_PRIO_F
-#define IDE3D_PC_PRIO_F 0
-#endif
-#ifndef IDE3D_PC_PRIO_B
-#define IDE3D_PC_PRIO_B 0
-#endif
+// Alternatives that were built and measured (profiles/round5/gather_experiments.txt); the constants select what is kept, the compiler drops the rest:
+constexpr bool IDE3D_PC_RWAVE = false;        // true: wave 7 is a dedicated region builder R (F = waves 4-6) — measured 1-2 us SLOWER (T wave 0 builds the table beside its taps): R alone needs a whole iteration for the table chain and is last at the barrier instead
+constexpr bool IDE3D_PC_VECTABLE = true;      // the region table's per-plane arithmetic on lanes 0-2 (build_region_table); false: all scalar (round 3)
+constexpr bool IDE3D_PC_DMA = true;           // the F waves fill the line buffers by LDS-DMA (stage_dma) instead of loads + ds_write
+constexpr int IDE3D_PC_PRIO_T = 0, IDE3D_PC_PRIO_T0 = 0, IDE3D_PC_PRIO_F = 0, IDE3D_PC_PRIO_B = 0;      // s_setprio per role: no effect in any combination
 
 #ifdef IDE3D_TT_TRACE
 #ifndef IDE3D_PC_TRACE_BLOCK
@@ -914,9 +868,9 @@ bool launch_triplane_tile(const float* planes, const int64_t* s, int n, int C, i
     if (group < 1) return false;
     const int chunks = steps / TT_DS;
     const int tiles_per_image = (rays_h / TT_EDGE) * (rays_w / TT_EDGE);
-    static const int env_segs = [] { const char* e = getenv("IDE3D_GATHER_SEGS"); return e ? atoi(e) : 0; }();
+    const int env_segs = knobs().gather_segs;
     // IDE3D_GATHER_PC=0: the 4-wave kernel with two workgroups per CU (rounds 1-2)
-    static const int pc_form = [] { const char* e = getenv("IDE3D_GATHER_PC"); return e ? atoi(e) : 8; }();      // 4 / 8: blending waves
+    const int pc_form = knobs().gather_pc;      // 4 / 8: blending waves
     const bool use_pc = pc_form == 4 || pc_form == 8;
     for (int n0 = 0; n0 < n; n0 += group) {
         const int cnt = (n - n0 < group) ? n - n0 : group;
@@ -966,18 +920,6 @@ const char* triplane_tile_build_flags() {
     return ""
 #ifdef IDE3D_TT_TRACE
         "IDE3D_TT_TRACE "
-#endif
-#if IDE3D_PC_EXP
-        "!IDE3D_PC_EXP=" IDE3D_STR(IDE3D_PC_EXP) " "
-#endif
-#if !IDE3D_PC_DMA
-        "IDE3D_PC_DMA=0 "
-#endif
-#if IDE3D_PC_RWAVE
-        "IDE3D_PC_RWAVE=1 "
-#endif
-#if !IDE3D_PC_VECTABLE
-        "IDE3D_PC_VECTABLE=0 "
 #endif
         ;
 }

@@ -16,6 +16,7 @@
 //    lanes run along the unit-stride axis (w for NCHW, c for channels_last) so global
 //    accesses stay coalesced.
 #include "common.h"
+#include "knobs.h"
 #include <type_traits>
 
 namespace ide3d {
@@ -480,7 +481,7 @@ fir44_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int tiles_x,
 
 // the conditions of fir44_kernel (see there)
 static bool fir44_applies(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep) {
-    const bool off = getenv("IDE3D_FIR_NO_LEAN") != nullptr;      // read per call: tests/test_gpu_ops.py flips it inside one process
+    const bool off = knob_live("IDE3D_FIR_NO_LEAN");      // read per call: tests/test_gpu_ops.py flips it inside one process
     if (off || p.dtype != IDE3D_F32 || p.f_w != 4 || p.f_h != 4 || p.up_x != 1 || p.up_y != 1 || p.down_x != 1 || p.down_y != 1) return false;
     if (p.x_stride[3] != 1 || p.y_stride[3] != 1 || ep.add || p.out_w <= 64 || (p.out_w & 3)) return false;
     const int64_t pitch = p.x_stride[2], w4 = (p.in_w + 3) & ~3;
@@ -625,7 +626,7 @@ fir_up2_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int tiles_
 }
 
 static bool fir_up2_applies(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep) {
-    const bool off = getenv("IDE3D_FIR_NO_LEAN") != nullptr;      // read per call: tests/test_gpu_ops.py flips it inside one process
+    const bool off = knob_live("IDE3D_FIR_NO_LEAN");      // read per call: tests/test_gpu_ops.py flips it inside one process
     if (off || p.dtype != IDE3D_F32 || p.f_w != 4 || p.f_h != 4 || p.up_x != 2 || p.up_y != 2 || p.down_x != 1 || p.down_y != 1) return false;
     if (p.x_stride[3] != 1 || p.y_stride[3] != 1 || (p.out_w & 3) || (p.in_w & 3)) return false;
     // a lane's four outputs start at ((floor(-pad_x0 / 2) + 2 k) * 2 + pad_x0: a multiple of 4 for even pads (upsample2d: 2), never for odd ones
