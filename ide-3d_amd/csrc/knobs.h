@@ -11,6 +11,7 @@
 //     IDE3D_COMPOSITE_NO_LDS  IDE3D_COMPOSITE_MODE=n           compositing kernel forms (composite.hip)
 //     IDE3D_FLR_GENERIC                                        filtered_lrelu: the runtime-parameterised kernel for every shape
 //     IDE3D_GATHER_NO_TILE  IDE3D_GATHER_SEGS=n  IDE3D_GATHER_PC=4|8|0   tri-plane gather forms (triplane.hip, triplane_tile.hip)
+//     IDE3D_MAPPING_PER_LAYER                                  mapping network as one launch per layer (the form of devices where the one-launch kernel is not co-resident)
 //   read PER CALL (`knob_live`): the five fallbacks that tests/ flip inside one process to compare a lean kernel with the form it replaced
 //     IDE3D_FIR_NO_LEAN  IDE3D_BIAS_ACT_NO_PLANES  IDE3D_MODCONV_NO_STRIP  IDE3D_MODCONV_NO_R16  IDE3D_MODCONV_PAIR=0|1
 #pragma once
@@ -29,6 +30,7 @@ struct Knobs {
     bool composite_no_lds; int composite_mode;
     bool flr_generic;
     bool gather_no_tile; int gather_segs, gather_pc;
+    bool mapping_per_layer;
 };
 
 inline const Knobs& knobs() {
@@ -53,6 +55,7 @@ inline const Knobs& knobs() {
         k.head_fp32 = on("IDE3D_MODCONV_HEAD_FP32"); k.head_no_small = on("IDE3D_HEAD_NO_SMALL"); k.head_no_resident = on("IDE3D_HEAD_NO_RESIDENT");
         k.composite_no_lds = on("IDE3D_COMPOSITE_NO_LDS"); k.composite_mode = num("IDE3D_COMPOSITE_MODE", 0);
         k.flr_generic = on("IDE3D_FLR_GENERIC");
+        k.mapping_per_layer = on("IDE3D_MAPPING_PER_LAYER");
         k.gather_no_tile = on("IDE3D_GATHER_NO_TILE"); k.gather_segs = num("IDE3D_GATHER_SEGS", 0); k.gather_pc = num("IDE3D_GATHER_PC", 8);
         return k;
     }();

@@ -16,6 +16,7 @@
 // grid-wide barrier (monotonic atomic counter; all MAP_WGS = 64 workgroups must be co-resident: checked against the occupancy query
 // on the host, and the spin is bounded).
 #include "common.h"
+#include "knobs.h"
 #include <atomic>
 
 namespace ide3d {
@@ -259,6 +260,83 @@ mapping_kernel(const MapArgs p) {
     }
 }
 
+// ---- one launch per layer (round 6) ----------------------------------------------------------------------------------------------
+// The same stages as mapping_kernel with a KERNEL BOUNDARY where that kernel has a grid barrier: launch l (0 <= l < layers) stages its input
+// (l = 0: the normalised z and embedded c; else layer l - 1's activations from the workspace), computes its slice of layer l with the same
+// gemv code (bit-identical results) and writes the workspace; launch `layers` broadcasts + truncates.  On MI355X a dependent kernel boundary
+// costs a few microseconds like the 64-workgroup barrier does (measured: a tie, see ide3d_mapping) — and nothing needs to be co-resident: this is
+// the form a device takes on which the one-launch kernel's workgroups would not all be resident.
+__global__ void __launch_bounds__(256)
+mapping_layer_kernel(const MapArgs p, int l) {
+    __shared__ __attribute__((aligned(16))) float s_x[MAP_MAX_N * MAP_MAX_K];
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    const int K0 = p.z_dim + p.embed;
+    constexpr int RB = 2;
+    const int wid = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const bool last = (l == p.layers);
+    const int K = (l == 0) ? K0 : p.fc_out[l - 1];
+    // this layer's weights first (they depend on nothing): in flight while the input is staged
+    float4 a_pre[MAP_NS][RB];
+    bool have_pre = false;
+    int r0 = 0, r1 = 0;
+    if (!last) {
+        const int O = p.fc_out[l], per = cdiv(O, nwg);
+        r0 = wg * per; r1 = min(O, r0 + per);
+        if (per <= nw * RB && p.n <= MAP_NB) {
+            const int i0 = r0 + wid * RB;
+            if (i0 < r1) gemv_load_block<RB>(a_pre, K, p.fc_w[l], i0, r1);
+            have_pre = true;
+        }
+    }
+    if (l == 0) {
+        for (int m = 0; m < p.n; ++m) {
+            float sq = 0.f;
+            for (int k = tid; k < p.z_dim; k += blockDim.x) { const float v = p.z[m * p.z_dim + k]; sq += v * v; }
+            const float zs = (p.z_dim > 0) ? rsqrtf(block_sum(sq, s_red) / (float)p.z_dim + 1e-8f) : 0.f;
+            for (int k = tid; k < p.z_dim; k += blockDim.x) s_x[m * MAP_MAX_K + k] = p.z[m * p.z_dim + k] * zs;
+            float sq2 = 0.f;
+            for (int e = tid; e < p.embed; e += blockDim.x) {
+                float acc = 0.f;
+                for (int k = 0; k < p.c_dim; ++k) acc += p.c[m * p.c_dim + k] * p.embed_w[e * p.c_dim + k];
+                const float v = acc * p.embed_wgain + (p.embed_b ? p.embed_b[e] * p.embed_bgain : 0.f);
+                s_x[m * MAP_MAX_K + p.z_dim + e] = v; sq2 += v * v;
+            }
+            const float es = (p.embed > 0) ? rsqrtf(block_sum(sq2, s_red) / (float)p.embed + 1e-8f) : 0.f;
+            for (int e = tid; e < p.embed; e += blockDim.x) s_x[m * MAP_MAX_K + p.z_dim + e] *= es;
+        }
+    } else {
+        const float* prev = p.act + (size_t)(l - 1) * MAP_MAX_N * MAP_MAX_K;
+        for (int i = tid * 4; i < p.n * K; i += blockDim.x * 4) {
+            const int m = i / K, k = i - m * K;
+            *reinterpret_cast<float4*>(s_x + m * MAP_MAX_K + k) = *reinterpret_cast<const float4*>(prev + m * MAP_MAX_K + k);
+        }
+    }
+    __syncthreads();
+    if (!last) {
+        float* out = p.act + (size_t)l * MAP_MAX_N * MAP_MAX_K;
+        if (have_pre) {
+            const int i0 = r0 + wid * RB;
+            if (i0 < r1) gemv_block<RB>(a_pre, s_x, p.n, K, p.fc_b[l], i0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
+        } else if (r0 < r1)
+            gemv_rows<2>(s_x, p.n, K, p.fc_w[l], p.fc_b[l], r0, r1, p.lr_mul * rsqrtf((float)K), p.lr_mul, p.alpha, p.act_gain, out, MAP_MAX_K);
+        return;
+    }
+    const int rows = p.n * p.num_ws;
+    for (int row = wg; row < rows; row += nwg) {
+        const int m = row / p.num_ws, j = row - m * p.num_ws;
+        const bool trunc = (p.psi != 1.0f) && j < p.cutoff;
+        for (int k = tid; k < K; k += blockDim.x) {
+            float v = s_x[m * MAP_MAX_K + k];
+            if (trunc) {                                                               // torch.lerp(w_avg, v, psi), ATen's two-sided formula
+                const float a = p.w_avg[k], d = v - a;
+                v = (fabsf(p.psi) < 0.5f) ? a + p.psi * d : v - d * (1.0f - p.psi);
+            }
+            p.ws[(size_t)row * K + k] = v;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace ide3d
 
@@ -288,11 +366,15 @@ static bool mapping_resident() {
     if (cached) cache[dev].store(ok ? 2 : 1, std::memory_order_relaxed);
     return ok;
 }
-extern "C" int ide3d_mapping_supported(void) { return mapping_resident() ? 1 : 0; }
+extern "C" int ide3d_mapping_supported(void) { return 1; }          /* (since round 6: the per-layer form needs no co-residency) */
 
 extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
     using namespace ide3d;
-    if (!mapping_resident()) { set_error("mapping: %d workgroups cannot be co-resident on this device (grid barrier)", MAP_WGS); return IDE3D_ENOKERNEL; }
+    // One launch with a grid barrier per layer where its 64 workgroups are co-resident (the occupancy query, with margin); else — a CU-masked or
+    // partitioned device, or IDE3D_MAPPING_PER_LAYER=1 — one launch per layer, same arithmetic.  Measured on MI355X (round 6, same box, bench.py):
+    // 901-903 frames/s at batch 4 / 591 at batch 1 in one launch, 904-906 / 586-590 per layer: a tie (a ~5 us dependent launch costs what a
+    // 64-workgroup barrier + the weight prefetch inside it costs).
+    const bool one_launch = !knobs().mapping_per_layer && mapping_resident();
     IDE3D_CHECK_ARG(q != nullptr, "mapping: null params");
     IDE3D_CHECK_ARG(q->n > 0 && q->n <= MAP_MAX_N, "mapping: batch must be 1..%d (got %d)", MAP_MAX_N, q->n);
     IDE3D_CHECK_ARG(q->layers >= 1 && q->layers <= MAP_MAX_LAYERS, "mapping: 1..%d layers", MAP_MAX_LAYERS);
@@ -320,6 +402,11 @@ extern "C" int ide3d_mapping(const ide3d_mapping_params* q, void* stream) {
     a.alpha = q->alpha; a.act_gain = q->act_gain; a.psi = q->truncation_psi;
     a.cutoff = (q->truncation_cutoff < 0) ? q->num_ws : q->truncation_cutoff;
     hipStream_t st = (hipStream_t)stream;
+    if (!one_launch) {
+        for (int l = 0; l <= q->layers; ++l) hipLaunchKernelGGL(mapping_layer_kernel, dim3(MAP_WGS), dim3(256), 0, st, a, l);
+        IDE3D_CHECK_LAUNCH("mapping (per layer)");
+        return IDE3D_OK;
+    }
     if (hipMemsetAsync(a.counter, 0, 2 * sizeof(unsigned), st) != hipSuccess) { set_error("mapping: hipMemsetAsync failed"); return IDE3D_ELAUNCH; }
     hipLaunchKernelGGL(mapping_kernel, dim3(MAP_WGS), dim3(256), 0, st, a);
     IDE3D_CHECK_LAUNCH("mapping");

@@ -570,8 +570,8 @@ typedef struct ide3d_mapping_params {
 } ide3d_mapping_params;
 
 int ide3d_mapping_workspace_bytes(void);
-/* 1 when the kernel's 64 workgroups are co-resident on the current device (its grid-wide barrier needs that; checked once against the
- * occupancy query with a 2x margin), else 0: `ide3d_mapping` then returns IDE3D_ENOKERNEL and callers use their layer-by-layer path. */
+/* Always 1 since round 6 (ABI 7): where the one-launch kernel's 64 workgroups are not co-resident on the current device (its grid-wide barrier needs that;
+ * checked against the occupancy query with a 2x margin) `ide3d_mapping` runs the same layers as one launch each. */
 int ide3d_mapping_supported(void);
 int ide3d_mapping(const ide3d_mapping_params* p, void* stream);
 

@@ -6,6 +6,7 @@ fp16 / bf16 storage 2e-3 / 2e-2 relative; tri-plane tap indices and in-bounds ma
 """
 
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1050,3 +1051,28 @@ def test_mapping_batch_sizes_across_the_one_block_threshold_agree(gpu_device):
     for n, r in rows.items():
         assert float((r.double() - want[0]).abs().max()) <= 2e-5 * scale, f'batch {n} vs the CPU definition'
         assert float((r - rows[1]).abs().max()) <= 4e-6 * scale, f'batch {n} vs batch 1: more than rounding'
+
+
+def test_mapping_per_layer_form_is_bit_equal(gpu_device, tmp_path):
+    """`ide3d_mapping` as one launch per layer (what a device takes on which the one-launch kernel's 64 workgroups are not co-resident;
+    IDE3D_MAPPING_PER_LAYER=1, read once per process) == the one-launch form, bit for bit: same gemv code, a kernel boundary for each grid barrier."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from training import triplane; from torch_utils import hip_plugin;"
+            "torch.manual_seed(0); G = triplane.TriPlaneGenerator().eval().requires_grad_(False).to('cuda:0');"
+            "z = torch.from_numpy(np.random.RandomState(1).randn(4, G.z_dim)).float().cuda();"
+            "c = triplane.conditioning_label('cuda:0').repeat(4, 1);"
+            "ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=8); assert hip_plugin.CALLS.get('mapping') == 1;"
+            "np.save(sys.argv[1], ws.cpu().numpy())") % (os.path.join(ROOT, 'ide-3d_amd'), ROOT)
+    outs = []
+    for flag in ('', '1'):
+        env = dict(os.environ)
+        env.pop('IDE3D_MAPPING_PER_LAYER', None)
+        if flag:
+            env['IDE3D_MAPPING_PER_LAYER'] = flag
+        path = str(tmp_path / f'ws{flag}.npy')
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=env, timeout=300)
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1])
