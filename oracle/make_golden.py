@@ -132,6 +132,23 @@ def gen_filtered_lrelu():
         dict(fu=None, fd=None, up=1, down=1, padding=0, clamp=0.5, shape=(1, 3, 5, 5)),
         dict(fu=f12, fd=None, up=2, down=1, padding=[6, 5, 6, 5], shape=(1, 1, 8, 8)),
     ]
+    # round 6: more reference-run shapes — the compile-time (up, down, taps) instances of csrc/filtered_lrelu.hip over several
+    # 32 x 32 tiles, ASYMMETRIC taps (a flip error shows), a non-separable 5 x 5 pair, every scalar option at once, odd sizes and paddings
+    a12 = r_upfirdn2d.setup_filter([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], separable=True)
+    a24 = r_upfirdn2d.setup_filter(list(range(1, 25)), separable=True)
+    a8 = r_upfirdn2d.setup_filter([1, 2, 3, 4, 5, 6, 7, 8], separable=True)
+    n5 = r_upfirdn2d.setup_filter([1, 2, 3, 2, 1], separable=False)
+    n5[0, 1] *= 3; n5 = n5 / n5.sum()                       # neither symmetric nor an outer product
+    specs += [
+        dict(fu=a12, fd=a12, up=2, down=2, padding=[10, 11, 10, 11], flip_filter=True, clamp=0.8, gain=1.3, slope=0.1, shape=(1, 2, 40, 40)),
+        dict(fu=a12, fd=a12, up=2, down=2, padding=[10, 11, 10, 11], shape=(1, 1, 37, 21)),
+        dict(fu=a12, fd=a12, up=4, down=2, padding=[11, 10, 12, 9], slope=0.25, shape=(1, 2, 12, 11)),
+        dict(fu=a24, fd=a12, up=4, down=2, padding=[17, 16, 17, 16], clamp=2.0, shape=(1, 1, 10, 13)),
+        dict(fu=a8, fd=a8, up=2, down=2, padding=[6, 7, 6, 7], gain=0.7, shape=(2, 2, 9, 9)),
+        dict(fu=None, fd=a12, up=1, down=2, padding=[5, 6, 5, 6], shape=(1, 2, 20, 18)),
+        dict(fu=a12, fd=a12, up=2, down=4, padding=[10, 11, 10, 11], shape=(1, 2, 16, 16)),
+        dict(fu=n5, fd=n5, up=2, down=2, padding=[3, 4, 4, 3], flip_filter=True, clamp=1.0, shape=(1, 2, 8, 9)),
+    ]
     for s in specs:
         shape = s.pop('shape')
         x = torch.randn(*shape, generator=g)
@@ -217,6 +234,20 @@ def gen_triplane():
         co[:, 1] = torch.tensor([-1.0 + 1.0 / H, 1.0 - 1.0 / H, 0.999999])
         out = r_util.sample_from_triplane(co, grid)
         cases.append(dict(cfg=dict(B=B, C=C, H=H, M=M), in_grid=grid, in_coords=co, out_feat=out))
+    # round 6: the generator's own channel count (32 per plane: the kernels' compiled width), a frustum-shaped ray grid the LDS-staged
+    # kernel tiles (8 x 8 rays x 4 steps), corner and far-outside coordinates (zeros padding, never clamped)
+    for (B, C, H, rays, steps, spread) in ((2, 32, 16, 8, 4, 0.55), (1, 32, 32, 16, 8, 1.6)):
+        grid = torch.randn(B, 3 * C, H, H, generator=g)
+        org = torch.tensor([0.05, -0.1, 2.7]) * spread / 1.6
+        px = torch.stack(torch.meshgrid(torch.linspace(-0.3, 0.3, rays), torch.linspace(0.3, -0.3, rays), indexing='xy'), -1).reshape(-1, 2)
+        d = torch.nn.functional.normalize(torch.cat([px, -torch.ones(rays * rays, 1) * 1.9], 1), dim=1)
+        t = torch.linspace(1.2, 2.9, steps) * spread
+        co = (org + d[:, None, :] * t[None, :, None]).reshape(1, -1, 3).repeat(B, 1, 1)
+        co = co + torch.randn(co.shape, generator=g) * 1e-3
+        co[:, 3] = torch.tensor([1.0, -1.0, 1.0]); co[:, 5] = torch.tensor([-3.0, 0.25, 1e6]); co[:, 7] = torch.tensor([37.0, -1e9, 0.5])      # (finite only: ATen's CPU and
+        # CUDA kernels disagree on non-finite coordinates — NaN vs 0 — so the reference has no answer to pin there)
+        out = r_util.sample_from_triplane(co, grid)
+        cases.append(dict(cfg=dict(B=B, C=C, H=H, M=co.shape[1], ray_grid=[rays, rays, steps]), in_grid=grid, in_coords=co, out_feat=out))
     save('triplane', cases)
 
 

@@ -271,6 +271,24 @@ def test_config3_full_size_grid_frame_vs_oracle(bench_generator, gpu_device, ora
             _frame_u8_check(cell, img_ref, seg_ref, f'frame {idx}, cell {k}')
 
 
+def test_two_live_video_jobs_on_one_generator_keep_their_own_planes(bench_generator, gpu_device):
+    """ADVICE r5: `gen_interp_frames` keeps a job's static tri-planes in buffers that outlive the job (so the next job replays the captured pass);
+    two LIVE jobs of one generator — interleaved iterators — must not share a pair: each frame equals the frame of the same job run alone."""
+    from training import video_render
+    G, _ = bench_generator
+    kw = dict(w_frames=8, grid_dims=(1, 1), psi=0.7, truncation_cutoff=14, device=gpu_device, ray_jitter=False)
+    alone = {s: [f.clone() for f in video_render.gen_interp_frames(G, [s], **kw)][:3] for s in (11, 12)}
+    a, b = video_render.gen_interp_frames(G, [11], **kw), video_render.gen_interp_frames(G, [12], **kw)
+    for i in range(3):
+        fa, fb = next(a), next(b)
+        assert torch.equal(fa, alone[11][i]), f'job A frame {i} was rendered from the other job\'s planes'
+        assert torch.equal(fb, alone[12][i]), f'job B frame {i}'
+    pool = video_render._plane_pool[G.synthesis]
+    assert sum(1 for e in pool if e[1]) == 2
+    a.close(); b.close()
+    assert sum(1 for e in pool if e[1]) == 0          # both pairs handed back: the next job reuses one (and the pass captured on it)
+
+
 def test_config4_sharded_items_full_size_vs_oracle(bench_generator, gpu_device, oracle_threads):
     """BASELINE config 4's item path where it runs (round 3): `render_grid_sharded(world=1)` at full size — 2 seeds x 8 camera poses,
     all poses of a seed from ONE cached backbone pass, batches of 4 items, fixed per-item jitter — against oracle frames of the same

@@ -346,9 +346,12 @@ def test_triplane_golden_and_layouts(golden, gpu_device):
     for cfg, a in golden('triplane'):
         grid, co = t(a['in_grid'], gpu_device), t(a['in_coords'], gpu_device)
         for g_ in (grid, grid.contiguous(memory_format=torch.channels_last)):
-            out = util.sample_from_triplane(co, g_)
+            out = util.sample_from_triplane(co, g_, ray_grid=False)
             assert_close(out, a['out_feat'], rtol=1e-5, atol=2e-6, what=str(cfg))
-    assert _calls('triplane_sample') == 6
+            if cfg.get('ray_grid'):          # round-6 cases: ray grids of the generator's channel count -> the LDS-staged kernel as well
+                out = util.sample_from_triplane(co, g_, ray_grid=tuple(cfg['ray_grid']))
+                assert_close(out, a['out_feat'], rtol=1e-5, atol=2e-6, what=str(cfg) + ' (tile kernel)')
+    assert _calls('triplane_sample') == 10 and _calls('triplane_sample_rays') == 4
 
 
 def test_triplane_tap_indices_bit_exact(gpu_device):
@@ -1064,7 +1067,7 @@ def test_mapping_per_layer_form_is_bit_equal(gpu_device, tmp_path):
             "torch.manual_seed(0); G = triplane.TriPlaneGenerator().eval().requires_grad_(False).to('cuda:0');"
             "z = torch.from_numpy(np.random.RandomState(1).randn(4, G.z_dim)).float().cuda();"
             "c = triplane.conditioning_label('cuda:0').repeat(4, 1);"
-            "ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=8); assert hip_plugin.CALLS.get('mapping') == 1;"
+            "torch.set_grad_enabled(False); ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=8); assert hip_plugin.CALLS.get('mapping') == 1;"
             "np.save(sys.argv[1], ws.cpu().numpy())") % (os.path.join(ROOT, 'ide-3d_amd'), ROOT)
     outs = []
     for flag in ('', '1'):

@@ -133,3 +133,18 @@ def test_per_image_transposed_layers_never_take_the_strip_plan():
             p = hip_plugin.modconv_plan(*shape, mode=2, per_image=True, arith=arith, epilogue='plain')
             assert p['strip'] == 0 and p['kind'] == 'fp32', (arith, shape, p)
     assert hip_plugin.modconv_plan(4, 128, 128, 128, 128, mode=2, per_image=False, epilogue='plain')['strip'] == 1
+
+
+def test_lowres_group_extent_by_batch_size():
+    """`ide3d_lowres_layers_supported` (host only): the low-resolution block group covers layers while all images' halo'd input maps of a layer,
+    as bf16 pieces of one 32-channel K slice, fit one CU's LDS beside the 55 KB weight slice (csrc/lowres.hip).  Layers of the 512-wide backbone
+    from 4^2: conv1@4, up@8, conv1@8, up@16, conv1@16, up@32, conv1@32."""
+    from torch_utils import hip_plugin
+    ups = [1, 2, 1, 2, 1, 2, 1]
+    fit = lambda n, arith=6: hip_plugin.LowresPlugin.layers_supported(n, 512, 4, ups, arith)
+    assert fit(1) == 6          # through the up-sampling layer to 32^2 (its input is 16^2: 324 slots); conv1@32 reads 34^2 = 1156 slots
+    assert fit(2) == 4 and fit(3) == 4 and fit(4) == 4          # through up@16 (input 8^2: n x 100 slots); conv1@16 reads n x 324
+    assert fit(5) == 4 and fit(8) == 2          # 8 images: conv1@4 and up@8 (8 x 36 slots); conv1@8 would read 800
+    assert fit(1, arith=3) >= 6          # bf16x3: two pieces per value, more room
+    assert fit(4, arith=1) == 0 and fit(4, arith=16) == 0          # exact fp32 products / f16x3 have no such form: per-layer path
+    assert hip_plugin.LowresPlugin.layers_supported(4, 500, 4, ups, 6) == 0          # C must be a multiple of 32
