@@ -28,4 +28,9 @@ bash scripts/pmc_kernels.sh $1/pmc_kernels > $O/pmc_kernels.log 2>&1
 cp $O/pmc_kernels/kernel_pmc.json $O/kernel_pmc.json 2>/dev/null
 python scripts/cut_pmc.py $O/kernel_pmc.json $O > /dev/null 2>&1
 rm -rf $O/pmc_kernels/p? $O/pmc_kernels.p?.log
+# round 6: the low-resolution block group — per-layer launches / one launch per phase / one persistent launch, same box, same binary — as bench
+# lines and as kernel timelines of one batch-1 image and one batch-4 step; the GPU's clocks / power (idle here; under load: `gpu_state` in the bench line)
+bash scripts/micro/r6_lowres_ab.sh $1/lowres_ab > $O/lowres_ab.txt 2>&1
+MODES="nogroup phases persistent" bash scripts/micro/r6_lowres_trace.sh $1/lowres_trace > /dev/null 2>&1
+rocm-smi --showclocks --showpower --showproductname > $O/rocm_smi_idle.txt 2>&1
 ls -la $O

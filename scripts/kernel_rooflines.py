@@ -234,7 +234,52 @@ def cases(device):
         conv_case(f'modconv 3x3 512->512 @{res} (low-res backbone)', 512, 512, res)
     for res in (32, 16, 8, 4):
         conv_case(f'modconv transposed 3x3 512->512 in@{res} (low-res backbone)', 512, 512, res, mode=2)
+    # the low-resolution block group (csrc/lowres.hip, round 6): the 4^2 .. 16^2 (batch 4) / .. 32^2 (batch 1) layers of the backbone as one
+    # launch per phase, against the per-layer launches it replaces.  flops = the covered 3x3 / transposed layers + heads
+    if hip_plugin.conv_arithmetic() in ('bf16x6', 'bf16x3'):
+        from training import networks as _nw
+        torch.manual_seed(0)
+        Gs = triplane.TriPlaneGenerator().eval().requires_grad_(False).to(device).synthesis
+        blocks = [getattr(Gs, f'vb{r}') for r in Gs.voxel_block_resolutions]
+        for nb in (N, 1):
+            wsb = Gs.split_ws(rn(nb, Gs.num_ws, 512))[0]
+            with torch.no_grad():
+                got = _nw.lowres_group_forward(blocks, wsb, noise_mode='const')
+            if got is None:
+                continue
+            nblk, resume = got[3], got[4]
+            fl = 0
+            for bi in range(nblk + (1 if resume else 0)):
+                r = 4 << bi
+                if bi > 0:
+                    fl += 2 * 512 * 512 * 9 * (r // 2) ** 2 * nb                      # transposed 3x3: 9 taps per INPUT position
+                if bi < nblk:
+                    fl += 2 * 512 * 512 * 9 * r * r * nb + 2 * 512 * 192 * r * r * nb      # conv1 + both heads
+            prod = ARITH_PRODUCTS.get(hip_plugin.conv_arithmetic(), 6)
+            for tag, env in (('group', None), ('per-layer launches', '1')):
+                def fn(wsb=wsb, env=env, nblk=nblk, resume=resume):
+                    if env: os.environ['IDE3D_NO_LOWRES_GROUP'] = env
+                    try:
+                        x = img = seg = None
+                        grp = _nw.lowres_group_forward(blocks, wsb, noise_mode='const')
+                        start, res_ = (grp[3], grp[4]) if grp else (0, False)
+                        if grp: x, img, seg = grp[:3]
+                        for i in range(start, nblk + (1 if resume else 0)):
+                            if i < nblk:
+                                x, img, seg = blocks[i](x, img, wsb[i], condition_img=seg, noise_mode='const', **(dict(_resume_after_conv0=True) if (res_ and i == start) else {}))
+                            elif not grp:
+                                x = blocks[i].conv0(x, wsb[i][:, 0], noise_mode='const')
+                    finally:
+                        os.environ.pop('IDE3D_NO_LOWRES_GROUP', None)
+                out.append((f'low-res block group 4^2..{4 << (nblk - 1)}^2{"+up" if resume else ""} batch {nb}: {tag} [{hip_plugin.conv_arithmetic()}]',
+                            'lr::phase_kernel' if env is None else 'modconv_split', f'mfma:{hip_plugin.conv_arithmetic()}', fl, fn))
     conv_case('conv 3x3 stride 2 64->128 in@257 (encoder)', 64, 128, 257, mode=1)
+    # the face parser of the editing loop (training/face_parsing.py): 32 folded conv+BN launches on the fp32 MFMA kernel + ATen glue, 512 x 512
+    from training import face_parsing as _fp
+    torch.manual_seed(1)
+    Pn = _fp.BiSeNet(20).eval().requires_grad_(False).to(device)
+    x_face = rn(1, 3, 512, 512)          # (a NEW name: the lambdas above close over `xi`, `nz`, `bb` by name)
+    out.append(('face parser BiSeNet 512x512 batch 1 (ResNet-18 context path: ~19 GFLOP)', 'modconv_kernel', 'mfma', 19.1e9, lambda: Pn(x_face)))
     for cin, cout, res in ((128, 192, 256), (256, 192, 128), (64, 22, 512), (128, 22, 256)):
         xx = rn(N, cin, res, res); ww = rn(N, cout, cin, 1, 1); bz = rn(cout)
         out.append((f'dual head 1x1 (per-image weights) {cin}->{cout} @{res}', 'modconv_kernel', 'hbm', (cin + cout) * res * res * N * 4,

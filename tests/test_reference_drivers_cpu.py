@@ -45,6 +45,13 @@ from training.volumetric_rendering import sample_camera_positions, create_cam2wo
 from dnnlib.seg_tools import *                            # gen_images.py:14 -> the REFERENCE's module through the extended package path
 assert legacy.__file__.startswith(ref) and dnnlib.__file__.startswith(overlay)
 assert sys.modules['dnnlib.seg_tools'].__file__.startswith(ref)
+# dnnlib/seg_tools.py:10 `from inversion.BiSeNet import BiSeNet` now finds the overlay's face parser; the rest of `inversion` stays the reference's
+import inversion.BiSeNet, inversion.networks
+assert inversion.BiSeNet.__file__.startswith(overlay) and inversion.networks.__file__.startswith(ref)
+assert sys.modules['dnnlib.seg_tools'].BiSeNet.__module__ == 'training.face_parsing'
+_net = BiSeNet(n_classes=20).eval()
+_lab = face_parsing(torch.zeros(1, 3, 64, 64), _net)          # the REFERENCE's face_parsing / parsing_img / id_remap / scatter (seg_tools.py:100-123) on it
+assert _lab.shape == (1, 19, 512, 512) and float(_lab.sum(1).min()) == 1.0
 import training.networks, training.triplane, torch_utils.ops.upfirdn2d
 for mod in (training.networks, training.triplane, torch_utils.ops.upfirdn2d, sys.modules['training.volumetric_rendering']):
     assert mod.__file__.startswith(overlay), mod.__file__
