@@ -249,11 +249,29 @@ struct FlsCfg {
     static constexpr int ZH = (TOH - 1) * DOWN + FDT;
     static constexpr int IW = (ZW + 2 * UP - 2) / UP + NTU + 1;                // input tile (covers every phase offset)
     static constexpr int IH = (ZH + 2 * UP - 2) / UP + NTU + 1;
-    static constexpr int N_IN = IW * IH, N_T = IH * ZW, N_Z = ZH * ZW, N_D = ZH * TOW;
-    static constexpr int OFF_T = (N_IN + 3) & ~3;
-    static constexpr int OFF_Z = (OFF_T + N_T + 3) & ~3;                       // s_d aliases s_in / s_t (dead once s_z is complete)
-    static constexpr int TOTAL = OFF_Z + N_Z;
-    static_assert(N_D <= OFF_Z, "the down-pass buffer must fit the space of the input and up-pass buffers");
+    // round 6: row pitches.  s_in rows are padded so that the horizontal up pass reads its window as 16-byte (up 2) / 8-byte (up 4) vectors, s_t rows
+    // to whole 8-column groups so that it writes two 16-byte vectors per item without a bounds check
+    static constexpr int P1_VEC = (UP == 2) ? 4 : 2;                           // floats per window read of the aligned horizontal pass
+    static constexpr int P1_STEP = 8 / UP;                                     // input columns per 8 z columns
+    static constexpr int P1_WIN = P1_STEP + NTU + 1;                           // window floats of an 8-column item
+    static constexpr int P1_READS = (P1_WIN + P1_VEC - 1) / P1_VEC;
+    static constexpr int ZWP = (ZW + 7) & ~7;                                  // s_t row pitch
+    static constexpr int P1_GROUPS = ZWP / 8;
+    static constexpr int IWP_MIN = (P1_GROUPS - 1) * P1_STEP + P1_READS * P1_VEC;
+    static constexpr int IWP = (((IW > IWP_MIN ? IW : IWP_MIN) + 3) & ~3);     // s_in row pitch
+    // s_d row pitch: the vertical down pass reads rows DOWN apart with 8 lanes per row (8 x 16 B = 128 B): a pitch of 32 floats puts every row of a
+    // 16-lane group on the same banks (2-way conflict on all 12 window reads per item); pitch = 16 (mod 32) floats alternates the bank halves
+    static constexpr int N_IN = IWP * IH, N_T = IH * ZWP, N_Z = ZH * ZW;
+    // LDS layout (round 6): [ s_t | s_z ] with s_in ALIASED onto the start of s_z (the input tile is dead once the horizontal up pass has run, s_z is
+    // first written by the pass after it) and s_d aliased onto s_t (dead once s_z is complete): 36.9 KB instead of 45.5 at (2, 2, 12, 12), i.e. FOUR
+    // workgroups per CU instead of three — the kernel issues vector instructions 61 % of the time at three waves per SIMD (kernel_pmc.json)
+    static constexpr int OFF_T = 0;
+    static constexpr int OFF_Z = ((N_T > ZH * TOW ? N_T : ZH * TOW) + 3) & ~3;          // (s_d may be the larger one: up 4)
+    static constexpr int OFF_IN = OFF_Z;
+    static constexpr int DP = (DOWN == 2 && ZH * (TOW + 16) <= OFF_Z) ? TOW + 16 : TOW;          // (where the padded rows still fit the aliased space)
+    static constexpr int N_D = ZH * DP;
+    static constexpr int TOTAL = OFF_Z + (N_Z > N_IN ? N_Z : N_IN);
+    static_assert(N_D <= OFF_Z, "the down-pass buffer must fit the space of the up-pass buffer");
 };
 
 template <class T, int UP, int DOWN, int FUT, int FDT, int SIGN>
@@ -261,7 +279,7 @@ __global__ void __launch_bounds__(256)
 filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_y) {
     using K = FlsCfg<UP, DOWN, FUT, FDT>;
     __shared__ __attribute__((aligned(16))) float lds[K::TOTAL];
-    float* const s_in = lds;
+    float* const s_in = lds + K::OFF_IN;
     float* const s_t = lds + K::OFF_T;
     float* const s_z = lds + K::OFF_Z;
     float* const s_d = lds;
@@ -283,47 +301,95 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
     const int ix0 = floordiv(zx0 - p.pad_x0, UP), iy0 = floordiv(zy0 - p.pad_y0, UP);
     const int rx0 = (zx0 - p.pad_x0) - UP * ix0, ry0 = (zy0 - p.pad_y0) - UP * iy0;     // phase of local z index 0, in [0, UP)
 
-    // ---- P0: input + bias -> LDS (zero outside the image); all loads issued before the first LDS write ----
+    // ---- P0: input + bias -> LDS (zero outside the image); all loads issued before the first LDS write.
+    // Round 6: lane = column, wave = row (+ 4 k): the row index and its validity are wave-uniform (scalar unit), the column's are computed once,
+    // the LDS address is one base + compile-time offsets — ~5 vector instructions per element instead of 27 (the flat index needed a division by
+    // the row length, four clamps and 64-bit address arithmetic per element: 245 of the kernel's ~1100 vector instructions per wave).
     {
         const T* xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
         const float bias = Elem<T>::ld((const T*)p.b + c);
-        constexpr int NL = (K::N_IN + 255) / 256;
-        float v[NL];
+        if constexpr (K::IWP <= 64) {
+            const int lane = tid & 63, wv = tid >> 6;
+            constexpr int NR = (K::IH + 3) / 4;
+            const int ix = ix0 + lane;
+            const bool col_ok = (unsigned)ix < (unsigned)p.in_w && lane < K::IW;
+            const int64_t col_off = (int64_t)min(max(ix, 0), p.in_w - 1) * p.x_stride[3];
+            float v[NR];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int i = tid + k * 256;
-            const int ly = i / K::IW, lx = i - ly * K::IW;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const int cy = min(max(iy, 0), p.in_h - 1), cx = min(max(ix, 0), p.in_w - 1);
-            const float t = Elem<T>::ld(xp + cy * p.x_stride[2] + cx * p.x_stride[3]);
-            v[k] = (iy == cy && ix == cx) ? t + bias : 0.f;
+            for (int k = 0; k < NR; ++k) {
+                const int ly = wv + 4 * k, iy = iy0 + ly;                        // wave-uniform
+                const bool row_ok = (unsigned)iy < (unsigned)p.in_h;
+                const float t = Elem<T>::ld(xp + (int64_t)min(max(iy, 0), p.in_h - 1) * p.x_stride[2] + col_off);
+                v[k] = (row_ok && col_ok) ? t + bias : 0.f;
+            }
+            if (lane < K::IWP) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) { const int ly = wv + 4 * k; if (ly < K::IH) s_in[ly * K::IWP + lane] = v[k]; }
+            }
+        } else {
+            constexpr int NL = (K::N_IN + 255) / 256;
+            float v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int i = tid + k * 256;
+                const int ly = i / K::IWP, lx = i - ly * K::IWP;
+                const int iy = iy0 + ly, ix = ix0 + lx;
+                const int cy = min(max(iy, 0), p.in_h - 1), cx = min(max(ix, 0), p.in_w - 1);
+                const float t = Elem<T>::ld(xp + cy * p.x_stride[2] + cx * p.x_stride[3]);
+                v[k] = (iy == cy && ix == cx && lx < K::IW) ? t + bias : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) { const int i = tid + k * 256; if (i < K::N_IN) s_in[i] = v[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < NL; ++k) { const int i = tid + k * 256; if (i < K::N_IN) s_in[i] = v[k]; }
     }
     __syncthreads();
 
     // ---- P1: horizontal up-FIR.  Thread item = (input row ly, group g): z columns j = 4 g - rx0 + e, e = 0..3, i.e. groups are
     // aligned to the polyphase grid (s = rx0 + j = 4 g + e), so phase and tap set of e are compile-time:
     //   first tap kx0 = (UP - e % UP) % UP, input column lx = ceil(s / UP) + t = 4 g / UP + ceil(e / UP) + t, taps kx0 + t UP.
-    {
+    // Round 6, when the tile starts on the polyphase grid (rx0 == 0: pad_x0 a multiple of UP — every StyleGAN3 layer): 8 columns per item, the
+    // window read as 16- / 8-byte vectors, two 16-byte stores, no bounds checks: 2 rounds of 48 multiply-adds + ~16 other instructions instead
+    // of 4 rounds of 24 + 42.
+    if (UP > 1 && rx0 == 0) {
+        for (int i = tid; i < K::IH * K::P1_GROUPS; i += 256) {
+            const int ly = i / K::P1_GROUPS, g = i - ly * K::P1_GROUPS;
+            const float* src = s_in + ly * K::IWP + g * K::P1_STEP;
+            float w[K::P1_READS * K::P1_VEC];
+#pragma unroll
+            for (int k = 0; k < K::P1_READS; ++k) {
+                if constexpr (K::P1_VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(src + 4 * k); w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+                else { const float2 q = *reinterpret_cast<const float2*>(src + 2 * k); w[2 * k] = q.x; w[2 * k + 1] = q.y; }
+            }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kx0 = (UP - e % UP) % UP, base = (e + UP - 1) / UP;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < K::NTU; ++t) acc += w[base + t] * fu[kx0 + t * UP];
+                o[e] = acc;
+            }
+            float* dst = s_t + ly * K::ZWP + 8 * g;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    } else {
         constexpr int NG = (K::ZW + UP - 1 + 3) / 4 + 1;            // groups covering j = -rx0 .. ZW - 1
         constexpr int WIN = 4 / UP + K::NTU;                        // distinct input columns a group touches (+1 when UP > 1)
         for (int i = tid; i < K::IH * NG; i += 256) {
             const int ly = i / NG, g = i - ly * NG;
-            const float* src = s_in + ly * K::IW + g * (4 / UP);
+            const float* src = s_in + ly * K::IWP + g * (4 / UP);
             float w[WIN + 1];
 #pragma unroll
             for (int k = 0; k < WIN + 1; ++k) w[k] = (g * (4 / UP) + k < K::IW) ? src[k] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                constexpr int dummy = 0; (void)dummy;
                 const int kx0 = (UP - e % UP) % UP, base = (e + UP - 1) / UP;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < K::NTU; ++t) acc += w[base + t] * fu[kx0 + t * UP];
                 const int j = 4 * g - rx0 + e;
-                if (j >= 0 && j < K::ZW) s_t[ly * K::ZW + j] = acc;
+                if (j >= 0 && j < K::ZW) s_t[ly * K::ZWP + j] = acc;
             }
         }
     }
@@ -334,27 +400,31 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
     {
         constexpr int NC = (K::ZH + UP - 1 + UP - 1) / UP + 1;       // cells covering jy = -ry0 .. ZH - 1
         constexpr int ZW4 = K::ZW / 4;
+        // round 6: the gain rides in the taps of this pass (one multiply per tap and thread at the start instead of one per z value), and the plain
+        // (no sign tensor) activation is 3 instructions per value: lrelu as max(v, v * slope) when 0 <= slope <= 1, the clamp as one v_med3
         const float zgain = (float)(UP * UP) * p.gain;
+        float fuz[FUT];
+#pragma unroll
+        for (int i = 0; i < FUT; ++i) fuz[i] = fu[i] * zgain;
+        const bool lrelu_max = p.slope >= 0.f && p.slope <= 1.f;
         const int64_t s_plane = (int64_t)plane * p.s_h * p.s_w_bytes;
         for (int i = tid; i < NC * ZW4; i += 256) {
             const int cy = i / ZW4, x4 = (i - cy * ZW4) * 4;
             float4 w[K::NTU + 1];
+            static_assert(NC - 1 + K::NTU < K::IH, "every window row of every cell lies inside the up-pass buffer");          // (no per-row guard: 4 selects per row)
 #pragma unroll
-            for (int k = 0; k < K::NTU + 1; ++k)
-                w[k] = (cy + k < K::IH) ? *reinterpret_cast<const float4*>(s_t + (cy + k) * K::ZW + x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < K::NTU + 1; ++k) w[k] = *reinterpret_cast<const float4*>(s_t + (cy + k) * K::ZWP + x4);
 #pragma unroll
             for (int r = 0; r < UP; ++r) {
                 const int jy = UP * cy - ry0 + r;
-                if (jy < 0 || jy >= K::ZH) continue;
+                const bool row_ok = (unsigned)jy < (unsigned)K::ZH;          // (only the stores are guarded: no branch between the rows of a cell)
                 const int ky0 = (UP - r % UP) % UP, base = (r + UP - 1) / UP;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < K::NTU; ++t) {
-                    const float f = fu[ky0 + t * UP];
+                    const float f = fuz[ky0 + t * UP];
                     v[0] += w[base + t].x * f; v[1] += w[base + t].y * f; v[2] += w[base + t].z * f; v[3] += w[base + t].w * f;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= zgain;
                 const int signX = zx0 + x4 + p.s_ofs_x, signY = zy0 + jy + p.s_ofs_y;
                 if (SIGN == 1) {
                     unsigned packed = 0;
@@ -366,26 +436,31 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
                         packed |= code << (2 * j);
                     }
                     const int sb = signX >> 2;          // signX is a multiple of 4 (tile origin and s_ofs_x are)
-                    if (signX >= 0 && sb < p.sw_limit && signY >= 0 && signY < p.s_h)
+                    if (row_ok && signX >= 0 && sb < p.sw_limit && signY >= 0 && signY < p.s_h)
                         p.s[s_plane + (int64_t)signY * p.s_w_bytes + sb] = (uint8_t)packed;
                 } else if (SIGN == 2) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int sx = signX + j;
-                        if (sx >= 0 && (sx >> 2) < p.sw_limit && (sx >> 2) < p.s_w_bytes && signY >= 0 && signY < p.s_h) {
+                        if (row_ok && sx >= 0 && (sx >> 2) < p.sw_limit && (sx >> 2) < p.s_w_bytes && signY >= 0 && signY < p.s_h) {
                             const unsigned code = (p.s[s_plane + (int64_t)signY * p.s_w_bytes + (sx >> 2)] >> ((sx & 3) << 1)) & 3u;
                             if (code & 1u) v[j] *= p.slope;
                             if (code & 2u) v[j] = 0.f;
                         }
                     }
                 } else {
+                    if (lrelu_max) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (v[j] < 0.f) v[j] *= p.slope;
-                        v[j] = fminf(fmaxf(v[j], -p.clamp), p.clamp);
+                        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaxf(v[j], v[j] * p.slope), -p.clamp, p.clamp);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (v[j] < 0.f) v[j] *= p.slope;
+                            v[j] = fminf(fmaxf(v[j], -p.clamp), p.clamp);
+                        }
                     }
                 }
-                *reinterpret_cast<float4*>(s_z + jy * K::ZW + x4) = make_float4(v[0], v[1], v[2], v[3]);
+                if (row_ok) *reinterpret_cast<float4*>(s_z + jy * K::ZW + x4) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -408,7 +483,7 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int k = 0; k < FDT; ++k) acc[e] += w[e * DOWN + k] * fd[k];
-            *reinterpret_cast<float4*>(s_d + zy * K::TOW + o4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(s_d + zy * K::DP + o4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
     __syncthreads();
@@ -422,7 +497,7 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
         float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < FDT; ++k) {
-            const float4 w = *reinterpret_cast<const float4*>(s_d + (o1 * DOWN + k) * K::TOW + o4);          // (o1 * DOWN + k <= (TOH - 1) DOWN + FDT - 1 = ZH - 1)
+            const float4 w = *reinterpret_cast<const float4*>(s_d + (o1 * DOWN + k) * K::DP + o4);          // (o1 * DOWN + k <= (TOH - 1) DOWN + FDT - 1 = ZH - 1)
             a[0] += w.x * fd[k]; a[1] += w.y * fd[k]; a[2] += w.z * fd[k]; a[3] += w.w * fd[k];
         }
         const int oy = oy0 + o1, ox = ox0 + o4;
