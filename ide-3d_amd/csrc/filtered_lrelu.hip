@@ -286,11 +286,18 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
     const int tid = threadIdx.x;
 
     // filters oriented for correlation (flipped unless p.flip), in registers (uniform loads)
+    // (round 6: one pointer + one signed step per filter instead of a select and a 64-bit multiply per tap: the scalar unit is shared by the CU's 16 waves and
+    // the prologue was ~400 scalar instructions per wave)
     float fu[FUT], fd[FDT];
+    {
+        const int64_t su = p.flip ? p.fu_stride[1] : -p.fu_stride[1], sd = p.flip ? p.fd_stride[1] : -p.fd_stride[1];
+        const float* bu = p.fu + (p.flip ? 0 : (FUT - 1) * p.fu_stride[1]);
+        const float* bd = p.fd + (p.flip ? 0 : (FDT - 1) * p.fd_stride[1]);
 #pragma unroll
-    for (int i = 0; i < FUT; ++i) fu[i] = p.fu[(p.flip ? i : FUT - 1 - i) * p.fu_stride[1]];
+        for (int i = 0; i < FUT; ++i) { fu[i] = *bu; bu += su; }
 #pragma unroll
-    for (int i = 0; i < FDT; ++i) fd[i] = p.fd[(p.flip ? i : FDT - 1 - i) * p.fd_stride[1]];
+        for (int i = 0; i < FDT; ++i) { fd[i] = *bd; bd += sd; }
+    }
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tix = bid % tiles_x; bid /= tiles_x;
@@ -309,18 +316,21 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
         const T* xp = (const T*)p.x + n * p.x_stride[0] + c * p.x_stride[1];
         const float bias = Elem<T>::ld((const T*)p.b + c);
         if constexpr (K::IWP <= 64) {
-            const int lane = tid & 63, wv = tid >> 6;
+            const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: the row arithmetic below then runs on the scalar unit)
             constexpr int NR = (K::IH + 3) / 4;
             const int ix = ix0 + lane;
             const bool col_ok = (unsigned)ix < (unsigned)p.in_w && lane < K::IW;
-            const int64_t col_off = (int64_t)min(max(ix, 0), p.in_w - 1) * p.x_stride[3];
+            const unsigned col_off = (unsigned)((int64_t)min(max(ix, 0), p.in_w - 1) * p.x_stride[3]);          // elements; a plane is < 2^32 elements
             float v[NR];
+            const T* rowp = xp + (int64_t)(iy0 + wv) * p.x_stride[2];          // scalar base (rows outside the image are replaced by row 0 before the load) + 32-bit lane offset
+            const int64_t row_step = 4 * p.x_stride[2];
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                const int ly = wv + 4 * k, iy = iy0 + ly;                        // wave-uniform
+                const int iy = iy0 + wv + 4 * k;                                 // wave-uniform
                 const bool row_ok = (unsigned)iy < (unsigned)p.in_h;
-                const float t = Elem<T>::ld(xp + (int64_t)min(max(iy, 0), p.in_h - 1) * p.x_stride[2] + col_off);
+                const float t = Elem<T>::ld((row_ok ? rowp : xp) + col_off);          // (a scalar select: every load is issued, none leaves the plane)
                 v[k] = (row_ok && col_ok) ? t + bias : 0.f;
+                rowp += row_step;
             }
             if (lane < K::IWP) {
 #pragma unroll
@@ -451,7 +461,8 @@ filtered_lrelu_sep_kernel(ide3d_filtered_lrelu_params p, int tiles_x, int tiles_
                 } else {
                     if (lrelu_max) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaxf(v[j], v[j] * p.slope), -p.clamp, p.clamp);
+                        for (int j = 0; j < 4; ++j)          // max(v, v * slope) as a median with +inf: fmaxf costs an extra canonicalising v_max per value
+                            v[j] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(v[j], v[j] * p.slope, __builtin_inff()), -p.clamp, p.clamp);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
