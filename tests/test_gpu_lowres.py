@@ -92,6 +92,24 @@ def test_group_equals_per_layer_path(gpu_device, C, nblocks, n, persistent):
     assert hip_plugin.exclusive_violations() == (0, '')
 
 
+def test_group_with_clamp_and_in_bf16x3(gpu_device):
+    """conv_clamp active in every layer and head (the fp16-block setting of a released pickle, inversion/networks.py:1058-1060), and the two-piece
+    arithmetic (bf16x3: PARTS = 2 instantiation of every phase) — each against the per-layer path in the same setting."""
+    from torch_utils import hip_plugin
+    for arith, tol in (('bf16x6', 1e-5), ('bf16x3', 2e-4)):
+        hip_plugin.conv_arithmetic(arith)
+        try:
+            blocks = _blocks(512, 3, 64, gpu_device, conv_clamp=0.6, seed=3)
+            ws_list = _split(blocks, torch.randn([2, sum(b.num_conv for b in blocks) + 1, 64], device=gpu_device))
+            xg, ig, sg, info = _run(blocks, ws_list, True)
+            assert info is not None
+            assert float(xg.abs().max()) <= 0.6 * 1.0000001 and float(info[3].abs().max()) > 0.3          # the clamp bites (act gain sqrt 2 on unit-variance data)
+            xr, ir, sr, _ = _run(blocks, ws_list, False)
+            assert _rel(xg, xr) < tol and _rel(ig, ir) < tol and _rel(sg, sr) < tol, (arith, _rel(xg, xr), _rel(ig, ir), _rel(sg, sr))
+        finally:
+            hip_plugin.conv_arithmetic('default')
+
+
 def test_group_outputs_at_its_own_boundary(gpu_device):
     """What leaves the group (x in front of the next block / conv0's output inside it, the skip images) against the per-layer path cut at the
     same place — a whole-backbone tolerance would hide an O(1) error of a sub-stage behind later layers."""
