@@ -52,7 +52,7 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY = 6.29e12           # B/s, measured copy ceiling (same guide)
 FP32_MFMA_PEAK = 157.3e12    # FLOP/s
 BATCH = 4                    # seeds per rank per step (BASELINE config 2)
-PROFILE_ROUND = 'round5'
+PROFILE_ROUND = 'round6'
 YAWS = (-0.5, 0.0, 0.5, 0.25)
 PARITY_JITTER_SEED = 11      # = oracle/make_bench_parity.py
 HEADLINE_ARITH = 'default'   # the library default (`ide3d_get_conv_arithmetic()` of a fresh process: bf16x6, fp32-grade) - what a drop-in caller runs
@@ -157,7 +157,7 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same launch shape (FETCH_SIZE doubled per the
     # gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE); null when the summary is absent.
     traffic, traffic_source = None, None
-    for rnd in (PROFILE_ROUND, 'round3', 'round2', 'round1'):
+    for rnd in (PROFILE_ROUND, 'round5', 'round3', 'round2', 'round1'):
         pmc = os.path.join(ROOT, 'profiles', rnd, 'gather_tile_pmc.json' if tiled else 'gather_pmc.json')
         if os.path.isfile(pmc):
             rec = json.load(open(pmc))
@@ -174,6 +174,46 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
                 per_launch_event_pairs_us=dict(avg=sum(ms) / len(ms) * 1e3, min=ms[0] * 1e3, median=ms[len(ms) // 2] * 1e3),
                 timed_launches=iters, warm_launches=warm_launches,
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
+
+
+def live_gather_traffic(tiled=True, timeout_s=150):
+    """HBM bytes per launch of the gather kernel from PMC counters collected IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE; `--kernel-trace` is the only trace domain beside them) over `scripts/gather_only.py` — the same launch shape, 3 + 3 + 3 launches —
+    in a child process while this one is idle; bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950: FETCH_SIZE reports half of a
+    16-byte-per-lane streaming read, MI355X_MICROARCH.md "HBM").  None + the reason when the profiler is absent, fails or times out."""
+    import csv, glob, shutil, signal, tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.isfile(exe):
+        return None, 'rocprofv3 not found'
+    if os.environ.get('ROCP_TOOL_LIBRARIES') or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'this process is itself running under rocprofv3'
+    tmp = tempfile.mkdtemp(prefix='ide3d_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    vals = {}
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            cmd = [exe, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', os.path.join(tmp, ctr), '--',
+                   sys.executable, os.path.join(ROOT, 'scripts', 'gather_only.py'), '3', 'tile' if tiled else 'flat', '3']
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)          # exactly the process group started here
+                pr.wait()
+                return None, f'rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s'
+            got = []
+            for f in glob.glob(os.path.join(tmp, ctr, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if 'triplane_sample' in r.get('Kernel_Name', '') and r.get('Counter_Name') == ctr:
+                        got.append(float(r['Counter_Value']))
+            if not got:
+                return None, f'rocprofv3 --pmc {ctr} pass returned no rows for the gather kernel (exit code {pr.returncode})'
+            vals[ctr] = (sum(got) / len(got), len(got))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = 2.0 * vals['FETCH_SIZE'][0] * 1024.0 + vals['WRITE_SIZE'][0] * 1024.0
+    return traffic, (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this bench.py (mean over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} "
+                     'launches of the same shape): 2 * FETCH_SIZE KB + WRITE_SIZE KB')
 
 
 # ---- CPU baseline --------------------------------------------------------------------------------------------------------------
@@ -399,6 +439,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-roofline-extra', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true', help='take roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc passes in this run')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-dropin', action='store_true', help='skip the batch-1 eager leg (gen_images.py loop shape)')
     ap.add_argument('--graph', type=int, default=1, help='replay G.mapping + G.synthesis from a captured hipGraph (0 = eager launches)')
@@ -700,8 +741,13 @@ def main():
             rf['timed_launches'] = rf_first['timed_launches'] + rf_late['timed_launches']
             full['roofline'] = rf
             full['roofline_both'] = {'at_start': rf_first, 'after_sustained_load': rf_late}
+            live, why = (None, 'disabled (--no-live-pmc)') if (args.no_live_pmc or world != 1) else live_gather_traffic()
+            if live is not None:
+                rf['traffic_committed'], rf['traffic'], rf['traffic_source'] = rf['traffic'], live, why
+            else:
+                rf['traffic_live_failed'] = why
             out['roofline'] = {'kernel': rf['kernel'], 'bound': 'hbm', 'achieved': r3(rf['achieved'], 1), 'peak': rf['peak'], 'unit': 'GB/s',
-                               'frac': r3(rf['frac'], 4), 'traffic': rf['traffic'], 'traffic_measured_in_this_run': False,
+                               'frac': r3(rf['frac'], 4), 'traffic': (int(rf['traffic']) if rf['traffic'] is not None else None), 'traffic_measured_in_this_run': live is not None,
                                'bytes_per_launch': rf['bytes_per_launch'], 'avg_launch_us': r3(rf['avg_launch_us'], 2), 'timed_launches': rf['timed_launches'],
                                'measured': 'twice in this run (first thing, and after everything else), 400 warm launches each; the MEAN of the two launch times is reported', **both}
         if not cpu and world == 1 and not args.no_roofline_extra:

@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 cp gpurun_out/bench_full.json $O/bench_default_full.json 2>/dev/null
-for A in fp32 f16x3; do python bench.py --steps 20 --warmup 5 --conv-arith $A --no-arith-sweep --no-roofline-extra --no-cpu-baseline > $O/bench_$A.json 2>/dev/null; done
+for A in fp32 f16x3; do python bench.py --steps 20 --warmup 5 --conv-arith $A --no-arith-sweep --no-roofline-extra --no-cpu-baseline --no-live-pmc > $O/bench_$A.json 2>/dev/null; done
 python scripts/kernel_rooflines.py --iters 20 --json $O/kernel_rooflines.json > $O/kernel_rooflines.txt 2>&1
 # BASELINE configs 3, 4 (one GPU), 5 and the encoder loop, in the library-default arithmetic (bf16x6 since round 4)
 python scripts/bench_video.py 120 > $O/bench_video.json 2> $O/bench_video.err
@@ -19,7 +19,7 @@ python scripts/bench_shapes.py > $O/bench_shapes.json 2> $O/bench_shapes.err
 python scripts/bench_dropin.py 90 > $O/bench_dropin.json 2> $O/bench_dropin.err
 python scripts/bench_dropin.py 90 --eager >> $O/bench_dropin.json 2>> $O/bench_dropin.err
 python scripts/bench_encoder.py > $O/bench_encoder.json 2> $O/bench_encoder.err
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-extra --no-arith-sweep > $O/bench_under_rocprof.json 2> $O/prof_bench.err )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-extra --no-arith-sweep --no-live-pmc > $O/bench_under_rocprof.json 2> $O/prof_bench.err )
 python scripts/step_breakdown.py $O/prof_bench $O/bench_step_breakdown.json > /dev/null 2>&1
 python scripts/step_timeline.py $O/prof_bench > $O/step_timeline.txt 2>/dev/null
 cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv 2>/dev/null
