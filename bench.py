@@ -176,11 +176,10 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 
 
-def live_gather_traffic(tiled=True, timeout_s=150):
-    """HBM bytes per launch of the gather kernel from PMC counters collected IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
-    WRITE_SIZE; `--kernel-trace` is the only trace domain beside them) over `scripts/gather_only.py` — the same launch shape, 3 + 3 + 3 launches —
-    in a child process while this one is idle; bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950: FETCH_SIZE reports half of a
-    16-byte-per-lane streaming read, MI355X_MICROARCH.md "HBM").  None + the reason when the profiler is absent, fails or times out."""
+def live_pmc(passes, script_argv, kernel_substr, timeout_s=150, env_extra=None):
+    """Counters of one kernel collected IN THIS RUN: one `rocprofv3 --pmc <counters>` pass per entry of `passes` (`--kernel-trace` is the only
+    trace domain beside them) over `python <script_argv>` in a child process while this one is idle.  Returns ({counter: mean per launch},
+    launches seen) or (None, reason) when the profiler is absent, fails or exceeds `timeout_s` per pass."""
     import csv, glob, shutil, signal, tempfile
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.isfile(exe):
@@ -188,32 +187,51 @@ def live_gather_traffic(tiled=True, timeout_s=150):
     if os.environ.get('ROCP_TOOL_LIBRARIES') or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
         return None, 'this process is itself running under rocprofv3'
     tmp = tempfile.mkdtemp(prefix='ide3d_pmc_', dir='/tmp')
-    env = dict(os.environ, TMPDIR='/tmp')
-    vals = {}
+    env = dict(os.environ, TMPDIR='/tmp', **(env_extra or {}))
+    vals, seen = {}, 0
     try:
-        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-            cmd = [exe, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', os.path.join(tmp, ctr), '--',
-                   sys.executable, os.path.join(ROOT, 'scripts', 'gather_only.py'), '3', 'tile' if tiled else 'flat', '3']
+        for i, ctrs in enumerate(passes):
+            cmd = [exe, '--pmc', *ctrs, '--kernel-trace', '--output-format', 'csv', '-d', os.path.join(tmp, f'p{i}'), '--', sys.executable, *script_argv]
             pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 pr.wait(timeout=timeout_s)
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, signal.SIGKILL)          # exactly the process group started here
                 pr.wait()
-                return None, f'rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s'
-            got = []
-            for f in glob.glob(os.path.join(tmp, ctr, '**', '*counter_collection.csv'), recursive=True):
+                return None, f'rocprofv3 --pmc {" ".join(ctrs)} pass exceeded {timeout_s} s'
+            got = {c: [] for c in ctrs}
+            for f in glob.glob(os.path.join(tmp, f'p{i}', '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if 'triplane_sample' in r.get('Kernel_Name', '') and r.get('Counter_Name') == ctr:
-                        got.append(float(r['Counter_Value']))
-            if not got:
-                return None, f'rocprofv3 --pmc {ctr} pass returned no rows for the gather kernel (exit code {pr.returncode})'
-            vals[ctr] = (sum(got) / len(got), len(got))
+                    if kernel_substr in r.get('Kernel_Name', '') and r.get('Counter_Name') in got:
+                        got[r['Counter_Name']].append(float(r['Counter_Value']))
+            if not all(got.values()):
+                return None, f'rocprofv3 --pmc {" ".join(ctrs)} pass returned no rows for {kernel_substr} (exit code {pr.returncode})'
+            for c, v in got.items():
+                vals[c] = sum(v) / len(v)
+                seen = max(seen, len(v))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    traffic = 2.0 * vals['FETCH_SIZE'][0] * 1024.0 + vals['WRITE_SIZE'][0] * 1024.0
-    return traffic, (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this bench.py (mean over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} "
-                     'launches of the same shape): 2 * FETCH_SIZE KB + WRITE_SIZE KB')
+    return vals, seen
+
+
+def live_gather_traffic(tiled=True):
+    """HBM bytes per launch of the gather kernel, measured in this run: bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950:
+    FETCH_SIZE reports half of a 16-byte-per-lane streaming read, MI355X_MICROARCH.md "HBM"; the two do not fit one pass)."""
+    vals, seen = live_pmc([('FETCH_SIZE',), ('WRITE_SIZE',)], [os.path.join(ROOT, 'scripts', 'gather_only.py'), '3', 'tile' if tiled else 'flat', '3'], 'triplane_sample')
+    if vals is None:
+        return None, seen
+    return 2.0 * vals['FETCH_SIZE'] * 1024.0 + vals['WRITE_SIZE'] * 1024.0, (
+        f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this bench.py (mean over {seen} launches of the same shape): 2 * FETCH_SIZE KB + WRITE_SIZE KB')
+
+
+def live_mfma_busy(kernel_name, arith):
+    """Matrix-pipe busy share of the governing convolution kernel, measured in this run over scripts/modconv_only.py (the layers' own shapes):
+    SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE) — busy cycles summed over 1024 SIMDs, GUI_ACTIVE over 8 XCDs (scripts/pmc_summarize.py)."""
+    vals, seen = live_pmc([('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')], [os.path.join(ROOT, 'scripts', 'modconv_only.py'), '2'], kernel_name,
+                          env_extra={'IDE3D_CONV_ARITH': arith})
+    if vals is None or not vals.get('GRBM_GUI_ACTIVE'):
+        return None, seen
+    return vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (128.0 * vals['GRBM_GUI_ACTIVE']), f'rocprofv3 --pmc pass run by this bench.py over scripts/modconv_only.py ({seen} launches of this kernel)'
 
 
 # ---- CPU baseline --------------------------------------------------------------------------------------------------------------
@@ -774,10 +792,13 @@ def main():
                     # template arguments <MODE, BIG, tile rows, PARTS, weight buffers, waves, F16>: bf16x6 = 3 pieces, f16x3 = 2 fp16 pieces, bf16x3 = 2 bf16 pieces
                     kname = {'bf16x6': 'modconv_split_kernel<0, 1, 16, 3, 2, 8, 0>', 'f16x3': 'modconv_split_kernel<0, 1, 16, 2, 2, 8, 1>', 'bf16x3': 'modconv_split_kernel<0, 1, 16, 2, 2, 8, 0>'}[arith]
                     busy = pm.get(kname)
+                    busy_live, busy_why = (None, 'disabled (--no-live-pmc)') if args.no_live_pmc else live_mfma_busy(kname, arith)
+                    full['roofline_step_pmc'] = {'mfma_busy_frac_live': busy_live, 'source': busy_why, 'committed': busy}
                     out['roofline_step'] = {'kernel': kname.replace(', ', ',') + ' (3x3 stride-1, 64^2..256^2 layers)', 'bound': f'mfma:{arith}', 'launches_per_step': 4,
                                             'us_per_step': r3(us, 1), 'share_of_step': r3(us / (med / args.steps * 1e6), 3), 'achieved': r3(fl / us / 1e6, 1), 'peak': r3(peak, 1),
                                             'unit': 'TFLOP/s', 'frac': r3(fl / us / 1e6 / peak, 3),
-                                            'mfma_busy_frac': None if busy is None else busy['mfma_busy_frac'], 'mfma_busy_measured_in_this_run': False}
+                                            'mfma_busy_frac': (r3(busy_live, 3) if busy_live is not None else None if busy is None else busy['mfma_busy_frac']),
+                                            'mfma_busy_measured_in_this_run': busy_live is not None}
             except Exception as e:
                 out['roofline_worst'] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not cpu and world == 1 and not args.no_cpu_baseline:
