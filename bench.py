@@ -176,7 +176,7 @@ def bench_gather(device, iters=100, tiled=True, warm_launches=400):
                 launch_shape=f'N={n} images x 1 tri-plane (C=32, 256x256), M=393216 samples/image')
 
 
-def live_pmc(passes, script_argv, kernel_substr, timeout_s=150, env_extra=None):
+def live_pmc(passes, script_argv, kernel_substr, timeout_s=90, env_extra=None):
     """Counters of one kernel collected IN THIS RUN: one `rocprofv3 --pmc <counters>` pass per entry of `passes` (`--kernel-trace` is the only
     trace domain beside them) over `python <script_argv>` in a child process while this one is idle.  Returns ({counter: mean per launch},
     launches seen) or (None, reason) when the profiler is absent, fails or exceeds `timeout_s` per pass."""

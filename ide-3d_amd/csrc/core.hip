@@ -61,7 +61,7 @@ bool exclusive_checked(const void* kernel, int threads, size_t dyn_lds, const ch
 extern "C" int ide3d_exclusive_violations(void) { return ide3d::g_excl_violations; }
 extern "C" const char* ide3d_exclusive_violation_text(void) { return ide3d::g_excl_text; }
 extern "C" const char* ide3d_last_error(void) { return ide3d::g_err; }
-extern "C" int ide3d_abi_version(void) { return 7; }
+extern "C" int ide3d_abi_version(void) { return 8; }
 extern "C" const char* ide3d_build_arch(void) { return "gfx950"; }
 extern "C" const char* ide3d_build_flags(void) {
     static char buf[512] = "";

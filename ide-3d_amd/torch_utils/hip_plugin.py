@@ -21,7 +21,7 @@ import weakref
 import torch
 
 _LIB_ENV = 'IDE3D_HIP_LIB'          # override path of libide3d_hip.so
-_ABI_VERSION = 7
+_ABI_VERSION = 8
 AMAX_SLOTS, AMAX_STRIDE = 32, 64     # = IDE3D_AMAX_SLOTS / _STRIDE (include/ide3d_hip.h): slot k of an image's `amax` row is element k * 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE
 
@@ -282,6 +282,8 @@ def load():
             'ide3d_set_conv_arithmetic': [i32],
             'ide3d_get_conv_arithmetic': [],
             'ide3d_frame_u8': [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+            'ide3d_sphere_points': [vp, vp, i32, ctypes.c_float, i32, vp, vp, vp],
+            'ide3d_cam2world': [vp, vp, vp, i32, i32, vp, vp],
             'ide3d_style_demod': [vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp],
             'ide3d_fold_heads': [vp, i64, i32, i32, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp],
             'ide3d_style_demod_batch': [ctypes.POINTER(_StyleJob), i32, i32, i32, vp],
@@ -308,7 +310,7 @@ EXPORTED_SYMBOLS = (
     'ide3d_filtered_lrelu', 'ide3d_filtered_lrelu_act', 'ide3d_triplane_sample', 'ide3d_triplane_sample_rays', 'ide3d_triplane_taps',
     'ide3d_triplane_sample_backward', 'ide3d_composite', 'ide3d_sample_pdf', 'ide3d_render_rays', 'ide3d_sample_voxel',
     'ide3d_lattice_points', 'ide3d_density_lattice',
-    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_modconv_plan', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_style_demod', 'ide3d_fold_heads',
+    'ide3d_modconv2d', 'ide3d_modconv_workspace_bytes', 'ide3d_modconv_plan', 'ide3d_set_conv_arithmetic', 'ide3d_get_conv_arithmetic', 'ide3d_frame_u8', 'ide3d_sphere_points', 'ide3d_cam2world', 'ide3d_style_demod', 'ide3d_fold_heads',
     'ide3d_style_demod_batch', 'ide3d_fold_heads_batch',
     'ide3d_skip_upsample_add_cl', 'ide3d_bilinear_up2_split', 'ide3d_mapping', 'ide3d_mapping_workspace_bytes', 'ide3d_mapping_supported',
     'ide3d_lowres_layers_supported', 'ide3d_lowres_workspace_bytes', 'ide3d_lowres_group',
@@ -1189,6 +1191,50 @@ class FramePlugin:
         return out
 
 
+class CameraPlugin:
+    """The pose helpers of training/volumetric_rendering.py as two launches (csrc/camera.hip)."""
+
+    @staticmethod
+    def applies(*tensors):
+        """float32 CUDA tensors outside autograd (the drivers' poses; a differentiable pose keeps the tensor operations)."""
+        return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and not t.requires_grad for t in tensors)
+
+    @staticmethod
+    def sphere_points(theta, pitch, r, pitch_is_v=False):
+        """theta, pitch [n, 1] -> (pos [n, 3], phi [n, 1]) (include/ide3d_hip.h: ide3d_sphere_points)."""
+        _require(theta.is_cuda and theta.dtype == torch.float32 and pitch.dtype == torch.float32 and pitch.device == theta.device and theta.numel() == pitch.numel(),
+                 'sphere_points: float32 CUDA tensors of one size required')
+        theta, pitch = theta.contiguous(), pitch.contiguous()
+        n = theta.numel()
+        pos = torch.empty([n, 3], dtype=torch.float32, device=theta.device)
+        phi = torch.empty_like(pitch)
+        with _dev_guard(theta.device):
+            rc = load().ide3d_sphere_points(_ptr(theta), _ptr(pitch), n, float(r), int(bool(pitch_is_v)), _ptr(pos), _ptr(phi), _stream(theta))
+        _check(rc, 'sphere_points')
+        return pos, phi
+
+    @staticmethod
+    def cam2world(forward, origin, lookat=None):
+        """forward [n, 3] | None, origin [n, 3], lookat [3] / [1, 3] / [n, 3] | None -> [n, 4, 4] (ide3d_cam2world)."""
+        _require(origin.is_cuda and origin.dtype == torch.float32 and origin.ndim == 2 and origin.shape[1] == 3, 'cam2world: origin must be float32 [n, 3] on a CUDA device')
+        origin = origin.contiguous()
+        n = origin.shape[0]
+        stride = 0
+        if lookat is not None:
+            _require(lookat.dtype == torch.float32 and lookat.device == origin.device and lookat.numel() in (3, 3 * n), 'cam2world: lookat must hold 3 or 3 n float32 values on the same device')
+            lookat = lookat.contiguous()
+            stride = 3 if (lookat.numel() == 3 * n and n > 1) else 0
+        else:
+            _require(forward is not None and forward.dtype == torch.float32 and forward.device == origin.device and tuple(forward.shape) == (n, 3),
+                     'cam2world: forward must be float32 [n, 3] on the same device')
+            forward = forward.contiguous()
+        out = torch.empty([n, 4, 4], dtype=torch.float32, device=origin.device)
+        with _dev_guard(origin.device):
+            rc = load().ide3d_cam2world(_ptr(forward if lookat is None else None), _ptr(origin), _ptr(lookat), stride, n, _ptr(out), _stream(origin))
+        _check(rc, 'cam2world')
+        return out
+
+
 class MappingPlugin:
     MAX_N, MAX_WIDTH, MAX_LAYERS = 8, 1024, 16
     _ws = {}          # (device index, launch domain) -> workspace tensor (per-layer activations + barrier counter); see workspace_scope
@@ -1390,6 +1436,7 @@ PLUGINS = {
     'volume_render_plugin': VolumeRenderPlugin,
     'modconv_plugin': ModconvPlugin,
     'frame_plugin': FramePlugin,
+    'camera_plugin': CameraPlugin,
     'style_plugin': StylePlugin,
     'resample_plugin': ResamplePlugin,
     'mapping_plugin': MappingPlugin,

@@ -14,6 +14,7 @@ parity tests) can supply the random draws instead of having them generated on th
 """
 
 import math
+import os
 import random
 
 import numpy as np
@@ -196,6 +197,14 @@ def truncated_normal_(tensor, mean=0, std=1):
     return tensor
 
 
+def _camera_plugin(*tensors):
+    """csrc/camera.hip for poses that are float32 device tensors outside autograd (`IDE3D_NO_CAMERA_KERNELS=1`: the tensor operations), else None."""
+    from torch_utils import hip_plugin
+    if not hip_plugin.CameraPlugin.applies(*tensors) or os.environ.get('IDE3D_NO_CAMERA_KERNELS'):
+        return None
+    return hip_plugin.CameraPlugin
+
+
 def sample_camera_positions(device, n=1, r=1, horizontal_stddev=0.3, vertical_stddev=0.155, horizontal_mean=math.pi * 0.5,
                             vertical_mean=math.pi * 0.5, mode='normal'):
     """Camera positions on a sphere of radius r.  theta = yaw, phi = pitch in (0, pi) (reference :147-193)."""
@@ -224,9 +233,13 @@ def sample_camera_positions(device, n=1, r=1, horizontal_stddev=0.3, vertical_st
         v = torch.clamp(v, 1e-5, 1 - 1e-5)
         phi = torch.arccos(1 - 2 * v)
     else:   # deterministic: the means
-        theta = torch.ones((n, 1), device=device, dtype=torch.float) * horizontal_mean
-        phi = torch.ones((n, 1), device=device, dtype=torch.float) * vertical_mean
+        theta = torch.full((n, 1), horizontal_mean, device=device, dtype=torch.float)
+        phi = torch.full((n, 1), vertical_mean, device=device, dtype=torch.float)
 
+    cam = _camera_plugin(theta, phi)
+    if cam is not None:          # clamp + spherical -> cartesian in one launch (csrc/camera.hip) instead of 14
+        pos, phi = cam.sphere_points(theta, phi, r)
+        return pos, phi, theta
     phi = torch.clamp(phi, 1e-5, math.pi - 1e-5)
     pos = torch.zeros((n, 3), device=device)
     pos[:, 0:1] = r * torch.sin(phi) * torch.cos(theta)
@@ -237,6 +250,9 @@ def sample_camera_positions(device, n=1, r=1, horizontal_stddev=0.3, vertical_st
 
 def create_cam2world_matrix(forward_vector, origin, device=None):
     """Look-along-`forward_vector` camera at `origin`, y-up: cam2world = T(origin) @ R([-left, up, -forward]) (reference :195-213)."""
+    cam = _camera_plugin(forward_vector, origin)
+    if cam is not None and forward_vector.ndim == 2 and forward_vector.shape == origin.shape and forward_vector.shape[1] == 3:
+        return cam.cam2world(forward_vector, origin)          # one launch instead of ~25
     forward_vector = normalize_vecs(forward_vector)
     world_up = device_const((0, 1, 0), torch.float, forward_vector.device if device is None else device).expand_as(forward_vector)
     left = normalize_vecs(torch.cross(world_up, forward_vector, dim=-1))
@@ -288,6 +304,10 @@ class LookAtPoseSampler:
                batch_size=1, device='cpu'):
         h = torch.randn((batch_size, 1), device=device) * horizontal_stddev + horizontal_mean
         v = torch.randn((batch_size, 1), device=device) * vertical_stddev + vertical_mean
+        cam = _camera_plugin(h, v, lookat_position) if torch.is_tensor(lookat_position) and lookat_position.numel() in (3, 3 * batch_size) else None
+        if cam is not None:      # the draws above keep torch's generator; everything after them is two launches (csrc/camera.hip)
+            origins, _ = cam.sphere_points(h, v, radius, pitch_is_v=True)
+            return cam.cam2world(None, origins, lookat=lookat_position)
         v = torch.clamp(v, 1e-5, math.pi - 1e-5)
         theta = h
         phi = torch.arccos(1 - 2 * (v / math.pi))

@@ -606,6 +606,25 @@ int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, int32_t h, in
 int ide3d_frame_u8(const float* img, const float* seg, const uint8_t* palette,
                    int32_t n, int32_t classes, int32_t H, int32_t W, uint8_t* out, void* stream);
 
+/*
+ * ABI 8.  The camera-pose helpers of training/volumetric_rendering.py as two launches (the reference spells them as ~45 one-element
+ * tensor operations per pose: ~0.3 ms of host time per image in gen_images.py:104-106 / gen_videos.py:120-124).  One thread per camera;
+ * every operation rounds on its own, in the reference's order.
+ *
+ * ide3d_sphere_points — the tail of `sample_camera_positions` (:186-193) and the middle of `LookAtPoseSampler.sample` (:281-291):
+ *   theta [n], pitch [n] float32 (the caller has drawn them: the random modes keep torch's generator);
+ *   pitch_is_v == 0: phi = clamp(pitch, 1e-5, pi - 1e-5);   pitch_is_v == 1: phi = arccos(1 - 2 * (clamp(pitch, ...) / pi));
+ *   pos [n, 3] = r * (sin phi cos theta, cos phi, sin phi sin theta);  phi_out [n] (may be NULL) = phi.
+ * ide3d_cam2world — `create_cam2world_matrix(forward_vector, origin)` (:195-213): out [n, 4, 4] = T(origin) @ R(columns -left, up, -forward)
+ *   with forward normalised, left = normalise(cross((0, 1, 0), forward)), up = normalise(cross(forward, left)).
+ *   lookat != NULL (LookAtPoseSampler :294-295): forward = normalise(lookat - origin) first (`forward` is ignored, may be NULL);
+ *   lookat_stride = 3 (one point per camera) or 0 (one point for all).
+ */
+int ide3d_sphere_points(const float* theta, const float* pitch, int32_t n, float r, int32_t pitch_is_v,
+                        float* pos, float* phi_out, void* stream);
+int ide3d_cam2world(const float* forward, const float* origin, const float* lookat, int32_t lookat_stride, int32_t n,
+                    float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

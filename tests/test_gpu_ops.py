@@ -667,6 +667,59 @@ def test_frame_u8(golden, gpu_device):
     assert np.array_equal(out, oracle_ops.frame_u8(img, seg))
 
 
+# ---- camera poses (csrc/camera.hip) ------------------------------------------------------------------------------------
+
+def test_camera_pose_kernels(golden, gpu_device, monkeypatch):
+    """`sample_camera_positions`, `create_cam2world_matrix`, `LookAtPoseSampler.sample` on device tensors = two launches (csrc/camera.hip):
+    the reference-run fixtures (volumetric_rendering.py:147-213, 268-295, run on the CPU) and the same functions spelled as tensor operations
+    (`IDE3D_NO_CAMERA_KERNELS=1`), every sampling mode under one generator state, one camera to several workgroups of them."""
+    import math
+    from training import volumetric_rendering as vr
+    from torch_utils import hip_plugin
+    dev = gpu_device
+    calls = lambda: (hip_plugin.CALLS.get('sphere_points', 0), hip_plugin.CALLS.get('cam2world', 0))
+    for cfg, a in golden('volumetric'):
+        before = calls()
+        if cfg['fn'] == 'gen_images_pose':
+            cam, phi, theta = vr.sample_camera_positions(dev, n=1, r=2.7, horizontal_mean=cfg['yaw'] + math.pi / 2, vertical_mean=math.pi / 2, mode=None)
+            assert_close(vr.create_cam2world_matrix(-cam, cam, device=dev), a['out_c2w'], rtol=0, atol=1e-6, what='c2w')
+            assert calls() == (before[0] + 1, before[1] + 1) and phi.shape == theta.shape == (1, 1)
+        elif cfg['fn'] == 'lookat':
+            c2w = vr.LookAtPoseSampler.sample(cfg['h'], cfg['v'], torch.tensor(cfg['lookat'], device=dev), radius=cfg['radius'], device=dev)
+            assert_close(c2w, a['out_c2w'], rtol=0, atol=2e-6, what='lookat')
+            assert calls() == (before[0] + 1, before[1] + 1)
+
+    def both(fn):
+        torch.manual_seed(5); random_state = __import__('random').getstate()
+        monkeypatch.delenv('IDE3D_NO_CAMERA_KERNELS', raising=False)
+        got = fn()
+        torch.manual_seed(5); __import__('random').setstate(random_state)
+        monkeypatch.setenv('IDE3D_NO_CAMERA_KERNELS', '1')
+        before = calls()
+        ref = fn()
+        assert calls() == before                                              # the switch really selects the tensor operations
+        monkeypatch.delenv('IDE3D_NO_CAMERA_KERNELS')
+        for g, r in zip(got if isinstance(got, tuple) else (got,), ref if isinstance(ref, tuple) else (ref,)):
+            assert g.shape == r.shape and g.dtype == r.dtype and g.device == r.device
+            assert_close(g, r, rtol=0, atol=3e-6, what=fn.__name__ if hasattr(fn, '__name__') else 'pose')
+
+    for n in (1, 5, 200):
+        for mode in (None, 'uniform', 'normal', 'hybrid', 'truncated_gaussian', 'spherical_uniform'):
+            both(lambda: vr.sample_camera_positions(dev, n=n, r=1.7, horizontal_stddev=0.4, vertical_stddev=0.2, horizontal_mean=1.1, vertical_mean=1.9, mode=mode))
+        g = torch.Generator().manual_seed(n)
+        fwd = torch.randn(n, 3, generator=g).to(dev); org = torch.randn(n, 3, generator=g).to(dev)
+        both(lambda: vr.create_cam2world_matrix(fwd, org, device=dev))
+        for lookat in (torch.tensor([0.0, 0.05, 0.2], device=dev), torch.tensor([[0.1, 0.0, -0.2]], device=dev), torch.randn(n, 3, generator=g).to(dev) * 0.1):
+            both(lambda: vr.LookAtPoseSampler.sample(1.3, 1.4, lookat, horizontal_stddev=0.3, vertical_stddev=0.2, radius=2.7, batch_size=n, device=dev))
+    # pitch outside (0, pi) is clamped like torch.clamp; a pose that takes part in autograd keeps the tensor operations
+    both(lambda: vr.sample_camera_positions(dev, n=3, r=1.0, horizontal_mean=0.3, vertical_mean=-4.0, mode=None))
+    both(lambda: vr.LookAtPoseSampler.sample(0.2, 7.0, torch.zeros(3, device=dev), radius=1.0, batch_size=2, device=dev))
+    before = calls()
+    fwd = torch.randn(2, 3, device=dev, requires_grad=True)
+    vr.create_cam2world_matrix(fwd, torch.zeros(2, 3, device=dev), device=dev).sum().backward()
+    assert calls() == before and fwd.grad is not None
+
+
 # ---- style preparation (affine styles, demodulation coefficients, folded head weights) ---------------------------------
 
 def test_style_demod_and_fold_heads_vs_formula(gpu_device):

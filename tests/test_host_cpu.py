@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     assert set(hip_plugin.EXPORTED_SYMBOLS) == set(declared)
     lib.ide3d_abi_version.restype = ctypes.c_int
     lib.ide3d_build_arch.restype = ctypes.c_char_p
-    assert lib.ide3d_abi_version() == hip_plugin._ABI_VERSION == 7
+    assert lib.ide3d_abi_version() == hip_plugin._ABI_VERSION == 8
     lib.ide3d_build_flags.restype = ctypes.c_char_p
     assert lib.ide3d_build_flags() == b'', 'the shipped library is a release build: no experiment knobs'
     assert lib.ide3d_build_arch() == b'gfx950'
