@@ -12,8 +12,8 @@
 //     IDE3D_FLR_GENERIC                                        filtered_lrelu: the runtime-parameterised kernel for every shape
 //     IDE3D_GATHER_NO_TILE  IDE3D_GATHER_SEGS=n  IDE3D_GATHER_PC=4|8|0   tri-plane gather forms (triplane.hip, triplane_tile.hip)
 //     IDE3D_MAPPING_PER_LAYER                                  mapping network as one launch per layer (the form of devices where the one-launch kernel is not co-resident)
-//   read PER CALL (`knob_live`): the five fallbacks that tests/ flip inside one process to compare a lean kernel with the form it replaced
-//     IDE3D_FIR_NO_LEAN  IDE3D_BIAS_ACT_NO_PLANES  IDE3D_MODCONV_NO_STRIP  IDE3D_MODCONV_NO_R16  IDE3D_MODCONV_PAIR=0|1
+//   read PER CALL (`knob_live`): the six fallbacks that tests/ flip inside one process to compare a lean kernel with the form it replaced
+//     IDE3D_FIR_NO_LEAN  IDE3D_FIR_NO_CELL  IDE3D_BIAS_ACT_NO_PLANES  IDE3D_MODCONV_NO_STRIP  IDE3D_MODCONV_NO_R16  IDE3D_MODCONV_PAIR=0|1
 #pragma once
 #include <stdlib.h>
 #include <string.h>

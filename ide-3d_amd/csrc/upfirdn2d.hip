@@ -155,6 +155,90 @@ upfirdn2d_generic_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cell kernel: up = U x U, no decimation, any (large) filter — one thread per output row of a cell of U x U outputs
+// ------------------------------------------------------------------------------------------------
+// The generic kernel walks the f_h f_w / U^2 taps of an output with two global loads per multiply-add; for the large filters the reference
+// sends through `upfirdn2d_kernel_large` (upfirdn2d.cu:25-108; viz/renderer.py:360 up-samples the viewer's image by 4 with 47 x 47 taps) that
+// is ~10 instructions per tap.  The U x U outputs of a cell (shifted outputs q U + j, j = 0 .. U - 1 per axis) read the SAME inputs
+// q .. q + ceil(f / U): input q + d meets phase j through tap k = d U - j, i.e. one input sample feeds U x U multiply-adds whose taps are
+// a contiguous U x U block of the filter.  The (flipped) filter sits in LDS, zero-padded to whole blocks, and is read as one 16-byte
+// broadcast per block row: 1 global load + U LDS reads per U^2 multiply-adds.  Every output adds its taps in the generic kernel's order
+// (ascending input row, then column); the padding taps add x * 0, so results are bit-equal to the generic kernel's for finite inputs
+// (tests/test_gpu_ops.py::test_upfirdn2d_cell_kernel_equals_generic).
+__host__ __device__ inline int cell_row_floats(int ntx, int U) { return ((ntx + 1 + 7) / 8) * 8 * U; }
+
+template <class T, int U>
+__global__ void __launch_bounds__(256)
+upfirdn2d_cell_kernel(ide3d_upfirdn2d_params p, ide3d_upfirdn2d_epilogue ep, int cells_x, int cells_y, int qx_min, int qy_min, int ntx, int nty) {
+    using M = typename Elem<T>::math_t;
+    extern __shared__ __attribute__((aligned(16))) float s_fpad[];          // [(nty + 1) U][FPW]: entry (a, b) = tap (a - (U - 1), b - (U - 1)), zero where no tap is
+    const int FPW = cell_row_floats(ntx, U), FPH = (nty + 1) * U;            // rows padded to whole batches of 8 blocks: the loop below never tests a tap
+    for (int e = threadIdx.x; e < FPW * FPH; e += 256) {
+        const int ky = e / FPW - (U - 1), kx = e % FPW - (U - 1);
+        float v = 0.f;
+        if (ky >= 0 && ky < p.f_h && kx >= 0 && kx < p.f_w) {
+            const int fy = p.flip ? ky : p.f_h - 1 - ky, fx = p.flip ? kx : p.f_w - 1 - kx;
+            v = p.f[(int64_t)fy * p.f_stride[0] + (int64_t)fx * p.f_stride[1]];
+        }
+        s_fpad[e] = v;
+    }
+    __syncthreads();
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    // one thread = one output ROW of a cell (U outputs): a small image (the viewer's 3 x 128 x 128 -> 512 x 512) has 49 152 cells, less than
+    // one wave per SIMD; per row it is three, and a thread's chain is a quarter as long
+    const int64_t total = (int64_t)p.n * p.c * cells_y * U * cells_x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int64_t r = idx;
+        const int cxi = (int)(r % cells_x); r /= cells_x;
+        const int jy = (int)(r % U); r /= U;
+        const int cyi = (int)(r % cells_y); r /= cells_y;
+        const int c = (int)(r % p.c), n = (int)(r / p.c);
+        const int qx = qx_min + cxi, qy = qy_min + cyi;
+        const int oy = qy * U + jy + p.pad_y0;
+        if (oy < 0 || oy >= p.out_h) continue;
+        M acc[U];
+#pragma unroll
+        for (int jx = 0; jx < U; ++jx) acc[jx] = 0;
+        const T* xp = x + n * p.x_stride[0] + c * p.x_stride[1];
+        for (int dy = 0; dy <= nty; ++dy) {
+            const int iy = qy + dy;
+            if (iy < 0 || iy >= p.in_h) continue;
+            const T* xr = xp + (int64_t)iy * p.x_stride[2];
+            const float* frow = s_fpad + (dy * U + U - 1 - jy) * FPW;
+            // the row's samples in batches of 8 loads in flight; a sample outside the image (or behind the last tap block: zero taps) enters as
+            // 0 instead of being skipped — the same sum, without a branch per sample (the loop is instruction-issue bound: few waves, 4 multiply-adds
+            // per sample)
+            const int s3 = (int)p.x_stride[3];
+            for (int dx0 = 0; dx0 <= ntx; dx0 += 8) {
+                M xv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ix = qx + dx0 + e;
+                    const bool ok = (unsigned)ix < (unsigned)p.in_w;
+                    const M v = Elem<T>::ld(xr + (ok ? ix : 0) * s3);
+                    xv[e] = ok ? v : (M)0;
+                }
+                const float* fb = frow + dx0 * U;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int jx = 0; jx < U; ++jx) acc[jx] += xv[e] * (M)fb[e * U + U - 1 - jx];
+                }
+            }
+        }
+#pragma unroll
+        for (int jx = 0; jx < U; ++jx) {
+            const int ox = qx * U + jx + p.pad_x0;
+            if (ox < 0 || ox >= p.out_w) continue;
+            const M out = apply_epilogue<T>(acc[jx] * (M)p.gain, ep, n, c, oy, ox, p.out_w);
+            Elem<T>::st(y + n * p.y_stride[0] + c * p.y_stride[1] + oy * p.y_stride[2] + ox * p.y_stride[3], out);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tile kernel (NCHW, compile-time up/down/filter)
 // ------------------------------------------------------------------------------------------------
 
@@ -681,6 +765,26 @@ static int launch_generic(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d
     return IDE3D_OK;
 }
 
+template <class T, int U>
+static int launch_cell(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
+    const int qx_min = floordiv(-p.pad_x0, U), qy_min = floordiv(-p.pad_y0, U);
+    const int cells_x = floordiv(p.out_w - 1 - p.pad_x0, U) - qx_min + 1, cells_y = floordiv(p.out_h - 1 - p.pad_y0, U) - qy_min + 1;
+    const int ntx = cdiv(p.f_w, U), nty = cdiv(p.f_h, U);
+    const size_t lds = (size_t)cell_row_floats(ntx, U) * (nty + 1) * U * sizeof(float);
+    const int64_t total = (int64_t)p.n * p.c * cells_y * U * cells_x;
+    hipLaunchKernelGGL((upfirdn2d_cell_kernel<T, U>), dim3(stream_grid(total, 256)), dim3(256), lds, st, p, ep, cells_x, cells_y, qx_min, qy_min, ntx, nty);
+    IDE3D_CHECK_LAUNCH("upfirdn2d_cell");
+    return IDE3D_OK;
+}
+// up-sampling by 2 x 2 / 4 x 4 without decimation through a filter of >= 36 taps that no tile instance covers (and whose padded copy fits 48 KB of LDS)
+static bool cell_applies(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep) {
+    if (knob_live("IDE3D_FIR_NO_CELL")) return false;
+    if (p.up_x != p.up_y || (p.up_x != 2 && p.up_x != 4) || p.down_x != 1 || p.down_y != 1 || ep.y_amax) return false;
+    if ((int64_t)p.f_w * p.f_h < 36) return false;
+    const int U = p.up_x;
+    return (int64_t)cell_row_floats(cdiv(p.f_w, U), U) * (cdiv(p.f_h, U) + 1) * U * 4 <= 48 * 1024 && p.x_stride[3] * (int64_t)p.in_w < (1ll << 31);
+}
+
 template <class T>
 static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilogue& ep, hipStream_t st) {
     const bool w_contig = (p.x_stride[3] == 1 && p.y_stride[3] == 1);
@@ -714,6 +818,9 @@ static int dispatch(const ide3d_upfirdn2d_params& p, const ide3d_upfirdn2d_epilo
                 if (p.up_y == 1 && p.down_y == 1) return launch_tile<T, 1, 1, 1, 1, 1, 12, 4, 4>(p, ep, st);
             }
         }
+    }
+    if constexpr (!std::is_same<T, double>::value) {
+        if (cell_applies(p, ep)) return p.up_x == 2 ? launch_cell<T, 2>(p, ep, st) : launch_cell<T, 4>(p, ep, st);
     }
     return launch_generic<T>(p, ep, st);
 }

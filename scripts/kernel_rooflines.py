@@ -123,7 +123,7 @@ def cases(device):
     f47 = upfirdn2d.setup_filter(np.outer(np.hanning(47), np.hanning(47)), device=device)
     xv = rn(1, 3, 128, 128)
     yv = upfirdn2d.upsample2d(xv, f47, up=4)
-    out.append(('FIR generic 47x47 up4 3ch 128->512 (viewer, viz/renderer.py:360)', 'upfirdn2d_generic', 'hbm',
+    out.append(('FIR 47x47 up4 3ch 128->512, cell kernel (viewer, viz/renderer.py:360)', 'upfirdn2d_cell', 'hbm',
                 (xv.numel() + yv.numel()) * 4, lambda: upfirdn2d.upsample2d(xv, f47, up=4)))
 
     # ---- a3 filtered_lrelu (StyleGAN3 layer shape, inversion/networks.py:576-597: up 2, down 2, 12-tap separable) -------

@@ -151,6 +151,38 @@ def test_upfirdn2d_tile_kernels(gpu_device, shape, kw, dtype, tol):
     assert_close(y.float(), ref, rtol=tol, atol=tol, what=f'{shape} {kw}')
 
 
+def test_upfirdn2d_cell_kernel_equals_generic(gpu_device, monkeypatch):
+    """Large 2-D filters with up = 2 x 2 / 4 x 4 (viz/renderer.py:360: 47 x 47 taps, up 4; the reference's `upfirdn2d_kernel_large`) run the
+    cell kernel (csrc/upfirdn2d.hip: one thread per U x U outputs, filter in LDS): bit-equal to the generic kernel — same taps, same order —
+    and equal to the oracle; odd filter sizes, shifted / cropping pads, flip, fp16, channels_last, the fused epilogue."""
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(12)
+    cases = [((1, 3, 128, 128), (47, 47), dict(up=4, padding=[25, 22, 25, 22], gain=16)),          # upsample2d(f47, up=4)
+             ((2, 5, 37, 29), (12, 12), dict(up=2, padding=[6, 5, 6, 5], gain=4)),
+             ((1, 4, 33, 50), (9, 7), dict(up=2, padding=[3, 4, 1, 7], flip_filter=True)),
+             ((2, 2, 40, 24), (8, 16), dict(up=4, padding=[-3, 9, 11, -2], gain=2.5)),                # negative pads crop
+             ((1, 3, 16, 16), (6, 6), dict(up=4, padding=[0, 0, 0, 0]))]
+    for shape, (fh, fw), kw in cases:
+        f = torch.randn(fh, fw, generator=g) / (fh * fw) ** 0.5
+        for dtype, tol in ((torch.float32, 2e-5), (torch.float16, 4e-3)):
+            for fmt in (torch.contiguous_format, torch.channels_last):
+                x = torch.randn(*shape, generator=g).to(dtype).to(gpu_device).contiguous(memory_format=fmt)
+                y = upfirdn2d.upfirdn2d(x, f.to(gpu_device), **kw)
+                monkeypatch.setenv('IDE3D_FIR_NO_CELL', '1')
+                y_gen = upfirdn2d.upfirdn2d(x, f.to(gpu_device), **kw)
+                monkeypatch.delenv('IDE3D_FIR_NO_CELL')
+                assert y.dtype == dtype and torch.equal(y, y_gen), f'{shape} {fh}x{fw} {kw} {dtype} {fmt}'
+                assert_close(y.float(), fast_ops.upfirdn2d(x.float().cpu().contiguous(), f, **kw), rtol=tol, atol=tol, what=f'{shape} {fh}x{fw} {kw} {dtype}')
+    # with the fused epilogue (skip add + noise + bias + lrelu + clamp)
+    from torch_utils import hip_plugin
+    x = torch.randn(2, 4, 20, 20, generator=g).to(gpu_device); f = (torch.randn(10, 10, generator=g) / 10).to(gpu_device)
+    add = torch.randn(2, 4, 40, 40, generator=g).to(gpu_device); nz = torch.randn(40, 40, generator=g).to(gpu_device); b = torch.randn(4, generator=g).to(gpu_device)
+    run = lambda: hip_plugin.Upfirdn2dPlugin.upfirdn2d_ex(x, f, 2, 2, 1, 1, 5, 4, 5, 4, False, 4.0, add=add, noise=nz, noise_strength=0.3, bias=b, act=3, alpha=0.2, act_gain=1.4, clamp=1.1)
+    y = run()
+    monkeypatch.setenv('IDE3D_FIR_NO_CELL', '1')
+    assert torch.equal(y, run())
+
+
 def test_upfirdn2d_views_never_read_past_their_storage(gpu_device):
     """the 16-byte staging path of the tile kernels reads whole aligned quads of a row, i.e. up to round_up(in_w, 4) - 1.  It
     may only run when that much of EVERY row is readable (`x_row_floats`, ABI 5): W-offset views whose last row ends the storage, H-strided
