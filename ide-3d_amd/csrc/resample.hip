@@ -115,6 +115,7 @@ skip_upsample_add_cl_kernel(const SkipArgs p) {
 struct BilinArgs {
     const float* x; int n, c, h, w;
     float* dst[3]; int c_begin[3], c_count[3];      // output k takes input channels [c_begin, c_begin + c_count)
+    int64_t bs[3];                                  // floats between images of output k
 };
 
 __global__ void __launch_bounds__(256)
@@ -147,7 +148,7 @@ bilinear_up2_split_kernel(const BilinArgs p) {
             const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
             o[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
         }
-        *reinterpret_cast<float4*>(p.dst[k] + (((int64_t)n * p.c_count[k] + cc) * H + Y) * W + X) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(p.dst[k] + (int64_t)n * p.bs[k] + ((int64_t)cc * H + Y) * W + X) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -173,7 +174,7 @@ extern "C" int ide3d_skip_upsample_add_cl(const float* lo, const int64_t lo_stri
 }
 
 extern "C" int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, int32_t h, int32_t w,
-                                        float* const dst[3], const int32_t c_begin[3], const int32_t c_count[3], void* stream) {
+                                        float* const dst[3], const int32_t c_begin[3], const int32_t c_count[3], const int64_t* dst_batch_floats, void* stream) {
     using namespace ide3d;
     IDE3D_CHECK_ARG(x && dst && c_begin && c_count, "bilinear_up2_split: null pointer");
     IDE3D_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0, "bilinear_up2_split: bad shape");
@@ -183,6 +184,9 @@ extern "C" int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, in
     int64_t total = 0;
     for (int k = 0; k < 3; ++k) {
         a.dst[k] = dst[k]; a.c_begin[k] = c_begin[k]; a.c_count[k] = c_count[k];
+        const int64_t dense = (int64_t)c_count[k] * 4 * h * w;
+        a.bs[k] = (dst_batch_floats && dst_batch_floats[k]) ? dst_batch_floats[k] : dense;
+        IDE3D_CHECK_ARG(a.bs[k] >= dense && a.bs[k] % 4 == 0, "bilinear_up2_split: batch stride of output %d is smaller than an image or not a multiple of 4 floats", k);
         IDE3D_CHECK_ARG(c_count[k] >= 0 && c_begin[k] >= 0 && c_begin[k] + c_count[k] <= c && (c_count[k] == 0 || dst[k]),
                         "bilinear_up2_split: channel range %d outside the input", k);
         IDE3D_CHECK_ARG(c_count[k] == 0 || (reinterpret_cast<uintptr_t>(dst[k]) & 15) == 0, "bilinear_up2_split: output %d is not 16-byte aligned", k);

@@ -292,7 +292,7 @@ def load():
             'ide3d_mapping_workspace_bytes': [],
             'ide3d_mapping_supported': [],
             'ide3d_skip_upsample_add_cl': [vp, ctypes.POINTER(i64 * 4), vp, ctypes.POINTER(i64 * 4), i32, i32, i32, i32, vp, vp],
-            'ide3d_bilinear_up2_split': [vp, i32, i32, i32, i32, ctypes.POINTER(vp * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(i32 * 3), vp],
+            'ide3d_bilinear_up2_split': [vp, i32, i32, i32, i32, ctypes.POINTER(vp * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(i32 * 3), ctypes.POINTER(ctypes.c_int64 * 3), vp],
             'ide3d_lowres_layers_supported': [i32, i32, i32, ctypes.POINTER(i32), i32, i32],
             'ide3d_lowres_workspace_bytes': [ctypes.POINTER(_LowresParams)],
             'ide3d_lowres_group': [ctypes.POINTER(_LowresParams), vp],
@@ -1323,18 +1323,28 @@ class ResamplePlugin:
         return out
 
     @staticmethod
-    def bilinear_up2_split(x, ranges):
-        """x [n, c, h, w] -> one [n, count, 2h, 2w] tensor per (begin, count) in `ranges` (at most 3), bilinear, align_corners=False."""
+    def bilinear_up2_split(x, ranges, adjacent=None):
+        """x [n, c, h, w] -> one [n, count, 2h, 2w] tensor per (begin, count) in `ranges` (at most 3), bilinear, align_corners=False.
+        `adjacent=(i, j)`: outputs i and j = i + 1 are the two channel ranges of ONE [n, count_i + count_j, 2h, 2w] tensor (views)."""
         _require(x.is_cuda and x.dtype == torch.float32, 'bilinear_up2_split: float32 CUDA tensor required')
         _require(1 <= len(ranges) <= 3, 'bilinear_up2_split: one to three channel ranges')
         x = x.contiguous()
         n, c, h, w = x.shape
-        outs = [torch.empty([n, cnt, 2 * h, 2 * w], dtype=torch.float32, device=x.device) for _b, cnt in ranges]
+        outs = [None if (adjacent and k in adjacent) else torch.empty([n, cnt, 2 * h, 2 * w], dtype=torch.float32, device=x.device) for k, (_b, cnt) in enumerate(ranges)]
+        bs = [0, 0, 0]
+        if adjacent:
+            i, j = adjacent
+            _require(j == i + 1 and 0 <= i and j < len(ranges), 'bilinear_up2_split: adjacent outputs must be consecutive')
+            ci, cj = ranges[i][1], ranges[j][1]
+            both = torch.empty([n, ci + cj, 2 * h, 2 * w], dtype=torch.float32, device=x.device)
+            outs[i], outs[j] = both[:, :ci], both[:, ci:]
+            bs[i] = bs[j] = (ci + cj) * 4 * h * w
         dst = (ctypes.c_void_p * 3)(*([o.data_ptr() for o in outs] + [0] * (3 - len(outs))))
+        bsa = (ctypes.c_int64 * 3)(*bs)
         beg = (ctypes.c_int32 * 3)(*([int(b) for b, _c in ranges] + [0] * (3 - len(outs))))
         cnt = (ctypes.c_int32 * 3)(*([int(c_) for _b, c_ in ranges] + [0] * (3 - len(outs))))
         with _dev_guard(x.device):
-            rc = load().ide3d_bilinear_up2_split(_ptr(x), n, c, h, w, ctypes.byref(dst), ctypes.byref(beg), ctypes.byref(cnt), _stream(x))
+            rc = load().ide3d_bilinear_up2_split(_ptr(x), n, c, h, w, ctypes.byref(dst), ctypes.byref(beg), ctypes.byref(cnt), ctypes.byref(bsa), _stream(x))
         _check(rc, 'bilinear_up2_split')
         return outs
 

@@ -378,8 +378,10 @@ class TriplaneSynthesisNetwork(torch.nn.Module):
         if (size == 2 * feat.shape[-1] and size == 2 * feat.shape[-2] and feat.shape[-1] % 2 == 0 and networks._inference_on_gpu(feat)
                 and networks._resample_init()):
             # one launch (csrc/resample.hip) instead of three ATen bilinear launches: same source-index rule and weights
+            # (raw RGB and semantic logits as the two channel ranges of one tensor: the first block's skip up-sampler then takes both in one launch,
+            # like every later block's, whose low-resolution pair is the previous dual head's output)
             x, img, seg = networks._resample_plugin.bilinear_up2_split(
-                feat, [(0, fc), (0, self.img_channels), (fc, feat.shape[1] - fc)])
+                feat, [(0, fc), (0, self.img_channels), (fc, feat.shape[1] - fc)], adjacent=(1, 2))
         else:
             up = lambda t: torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', align_corners=False)
             x = up(feat[:, :fc])

@@ -592,9 +592,11 @@ int ide3d_skip_upsample_add_cl(const float* lo, const int64_t lo_stride[4], cons
  * split into up to three dense NCHW outputs: dst[k] [n, c_count[k], 2h, 2w] takes input channels c_begin[k] ...
  * (the composited 64x64 feature image -> colour features / raw RGB / semantic logits of the super-resolution blocks,
  * SURVEY.md Appendix B; ATen source-index rule `area_pixel_compute_source_index`).  c_count[k] == 0 skips output k.
+ * ABI 8: dst_batch_floats (may be NULL = all dense) — floats between consecutive images of output k, 0 = dense (c_count[k] * 2h * 2w): outputs that
+ * are channel ranges of ONE tensor (raw RGB | semantic logits, which the skip up-sampler of the next block then reads in one launch).
  */
 int ide3d_bilinear_up2_split(const float* x, int32_t n, int32_t c, int32_t h, int32_t w,
-                             float* const dst[3], const int32_t c_begin[3], const int32_t c_count[3], void* stream);
+                             float* const dst[3], const int32_t c_begin[3], const int32_t c_count[3], const int64_t* dst_batch_floats, void* stream);
 
 /*
  * `mask2color(seg)` (dnnlib/seg_tools.py:75-81: argmax over the class channel + palette) and

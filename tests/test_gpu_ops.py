@@ -1047,6 +1047,11 @@ def test_bilinear_up2_split(gpu_device):
             want = torch.nn.functional.interpolate(x[:, b:b + cnt], size=(2 * h, 2 * w), mode='bilinear', align_corners=False)
             assert o.shape == want.shape
             assert_close(o, want, rtol=1e-6, atol=1e-6, what=f'bilinear channels {b}+{cnt}')
+        if len(ranges) == 3:          # outputs 1 and 2 as the two channel ranges of one tensor (what the super-resolution path asks for): same values
+            adj = hip_plugin.ResamplePlugin.bilinear_up2_split(x.to(gpu_device), ranges, adjacent=(1, 2))
+            assert adj[1]._base is adj[2]._base and adj[1]._base.shape[1] == ranges[1][1] + ranges[2][1]
+            for o, a_ in zip(outs, adj):
+                assert torch.equal(o, a_)
 
 
 # ---- mapping network in one launch (csrc/mapping.hip) ---------------------------------------------------------------------
