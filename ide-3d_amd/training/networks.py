@@ -1024,7 +1024,7 @@ class SegSynthesisBlock(torch.nn.Module):
                     y_seg = self.toseg(x, w_shared, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
                 lo_both, y_both = _adjacent_views(img_lo, seg_lo), _adjacent_views(y, y_seg)
                 if (lo_both is not None and y_both is not None and img is None and seg is None and not getattr(self, 'skip_channels_last', False)
-                        and not os.environ.get('IDE3D_NO_SKIP_MERGE')):
+                        and not self.is_last and not os.environ.get('IDE3D_NO_SKIP_MERGE')):          # (the network's outputs stay dense tensors of their own, like the reference's)
                     # both skip images in ONE up-sample + add launch: they are channel ranges of one tensor (the dual head's output,
                     # the previous block's accumulation) all the way through the backbone
                     both = self._accumulate(lo_both, None, y_both)
