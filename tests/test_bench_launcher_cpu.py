@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = ['--steps', '1', '--warmup', '1', '--blocks', '3', '--dry-run-cpu']
@@ -114,3 +115,19 @@ def test_compact_line_of_a_full_size_gpu_record():
     out['roofline_worst'] = [{'kernel': 'k' * 60, 'frac': 0.1} for _ in range(80)]
     rec = _strict(bench.compact_line(out))
     assert 'roofline_worst' in rec['dropped_for_size'] and 'roofline' in rec and 'cpu_baseline' in rec and rec['value'] == big
+
+
+def test_live_pmc_passes_degrade_to_a_reason():
+    """`bench.live_pmc` (the rocprofv3 counter passes bench.py runs itself for `roofline.traffic` / `roofline_step.mfma_busy_frac`) never raises and
+    never hangs the bench: without a GPU, without the profiler or without rows for the kernel it returns (None, reason) and the committed figure is
+    quoted with `traffic_measured_in_this_run: false`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t0 = time.time()
+    vals, why = bench.live_pmc([('FETCH_SIZE',)], ['-c', 'print(1)'], 'no_such_kernel', timeout_s=60)
+    assert vals is None and isinstance(why, str) and why
+    traffic, why = bench.live_gather_traffic()
+    assert traffic is None and isinstance(why, str) and why
+    busy, why = bench.live_mfma_busy('modconv_split_kernel<0, 1, 16, 3, 2, 8, 0>', 'bf16x6')
+    assert busy is None and isinstance(why, str) and why
+    assert time.time() - t0 < 170
